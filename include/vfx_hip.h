@@ -1,0 +1,183 @@
+/*
+ * vfx_hip.h -- C ABI of libvfx_hip.so, the MI355X (gfx950) kernel library behind
+ * voicefixer_amd.VoiceFixer.restore()/restore_inmem() and Vocoder.forward()/oracle().
+ *
+ * The reference (haoheliu/voicefixer) has no FFI: its hot path is a chain of stock torch
+ * operators.  Each entry point below replaces the torch operator calls named in its
+ * comment (paths relative to the reference root).  What a reference maintainer would bind
+ * is shown in INTEGRATION.md (ctypes stubs).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. a torch tensor's
+ *     data_ptr()), float32 unless stated, never retained after the call returns;
+ *   - activations are channel-major: element (b, c, l) of a vfx_tensor lives at
+ *     ptr[b*bstride + c*cstride + l*lstride] (strides in ELEMENTS). Inputs of the conv
+ *     family need lstride == 1, cstride % 4 == 0 and a 16-byte aligned ptr;
+ *   - 2-D feature maps (B,C,H,W) are stored flattened with a power-of-two row pitch
+ *     P = W+1: element (h, w) at l = h*P + w; column P-1 is a structural zero that serves
+ *     as left/right zero padding for 3x3 convolutions (the UNet works on W = 127, 63, ...
+ *     1 mel bins, so P = 128, 64, ... 2);
+ *   - all launches go to `stream` (a hipStream_t passed as void*), no internal
+ *     synchronisation, no allocation; thread-safe for distinct streams;
+ *   - return 0 on success, a negative VFX_E* code for bad arguments, or a positive
+ *     hipError_t from the launch.  Nothing throws.
+ */
+#ifndef VFX_HIP_H
+#define VFX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vfx_stream_t; /* hipStream_t */
+
+#define VFX_OK 0
+#define VFX_EINVAL (-1)   /* bad argument / unsupported shape */
+#define VFX_EALIGN (-2)   /* pointer or stride alignment */
+#define VFX_ERANGE (-3)   /* tile bookkeeping overflow (tap span too large for the tile) */
+
+typedef struct {
+    void* ptr;
+    int64_t bstride, cstride, lstride; /* element strides */
+} vfx_tensor;
+
+/* pre-activation applied to the INPUT while it is staged into LDS */
+#define VFX_PRE_NONE 0
+#define VFX_PRE_LRELU 1         /* leaky_relu(x, pre_slope) */
+#define VFX_PRE_AFFINE_LRELU 2  /* leaky_relu(x*pre_scale[c] + pre_shift[c], pre_slope): eval BatchNorm + (leaky)ReLU */
+/* post-activation applied in the epilogue, after bias and residual */
+#define VFX_POST_NONE 0
+#define VFX_POST_LRELU 1        /* leaky_relu(., post_slope) */
+#define VFX_POST_ELU 2
+#define VFX_POST_TANH 3
+#define VFX_POST_SIGMOID 4
+#define VFX_POST_LRELU_SNAKE 5  /* v = leaky_relu(., post_slope); v + sin(v)  (UpsampleNet prologue fused upstream) */
+
+typedef struct {
+    int pre_act;
+    float pre_slope;
+    const float* pre_scale; /* [Cin] for VFX_PRE_AFFINE_LRELU */
+    const float* pre_shift; /* [Cin] */
+    int post_act;
+    float post_slope;
+} vfx_act;
+
+#define VFX_PAD_ZERO 0
+#define VFX_PAD_REFLECT 1
+
+int vfx_version(void);
+
+/* Number of hipLaunchKernel calls issued by this library in this process (test hook:
+ * proves the HIP path, not a fallback, produced a result). */
+uint64_t vfx_launch_count(void);
+
+/* ---- convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
+ * Weights are pre-packed on the host as [slab][CinPad][Cout] (Cout contiguous), where a
+ * slab is one kernel tap, CinPad = Cin rounded up to 8 (zero filled).  See
+ * voicefixer_amd/packing.py.  bias may be NULL; res may be NULL.                      */
+
+/* y[b,n,l] = post( bias[n] + res[b,n,l] + sum_{c,t} w[t][c][n] * pre(x[b,c,l+(t-(k-1)/2)*dil]) )
+ * Replaces torch conv1d (+ leaky_relu / ELU / tanh / ReflectionPad1d around it) in
+ * voicefixer/vocoder/model/generator.py:33-54,74-76,95-99 and modules.py:549-576
+ * (ResStack), and torch linear in voicefixer/restorer/model.py:69-99 (k = 1).
+ * Cout % 32 == 0; for Cout == 1 use vfx_conv1d_cout1_f32. */
+int vfx_conv1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
+                   const vfx_tensor* res, const vfx_tensor* y, int B, int Cin, int Cout, int L,
+                   int k, int dilation, int pad_mode, const vfx_act* act, vfx_stream_t stream);
+
+/* ConvTranspose1d(Cin, Cout, kernel 2s, stride s, padding s/2 + s%2, output_padding s%2):
+ * Lin -> s*Lin.  Polyphase: s phases x 2 taps.  w_packed = [2s][CinPad][Cout], slab k is
+ * kernel tap k.  Replaces voicefixer/vocoder/model/modules.py:449-459,519 (UpsampleNet.layer). */
+int vfx_convtr1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
+                     const vfx_tensor* y, int B, int Cin, int Cout, int Lin, int stride,
+                     const vfx_act* act, vfx_stream_t stream);
+
+/* Conv2d ksize x ksize (ksize 1 or 3, padding ksize/2, stride 1) on pitch-P maps, P = 1<<pitch_log2,
+ * W = P-1.  w_packed = [ksize*ksize][CinPad][Cout], slab ky*ksize+kx.  Output pad column is
+ * written as zero.  Replaces voicefixer/restorer/modules.py:18-26,33-41,47-53 (ConvBlockRes). */
+int vfx_conv2d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
+                   const vfx_tensor* res, const vfx_tensor* y, int B, int Cin, int Cout, int H,
+                   int pitch_log2, int ksize, const vfx_act* act, vfx_stream_t stream);
+
+/* ConvTranspose2d 3x3 stride 2 padding 0 followed by the reference's prune of the last
+ * output row: (h, w=P-1) -> (2h, 2w+1) on pitch 2P.  w_packed = [9][CinPad][Cout], slab
+ * ky*3+kx.  Replaces voicefixer/restorer/modules.py:112-121,141-150 (DecoderBlockRes). */
+int vfx_convtr2d_3x3s2_f32(const vfx_tensor* x, const float* w_packed, const vfx_tensor* y,
+                           int B, int Cin, int Cout, int h, int in_pitch_log2,
+                           const vfx_act* act, vfx_stream_t stream);
+
+/* Cout == 1 convolution (channel reduction, HBM-bound): y[b,0,l] = post(bias + sum w[c][t] * x[b,c,l+t-(k-1)/2]),
+ * w = [Cin][k].  Replaces the final ReflectionPad1d(3)+Conv1d(64,1,7)+Tanh
+ * (generator.py:95-99) and UNet after_conv2 1x1 (restorer/model_kqq_bn.py:119-126,174). */
+int vfx_conv1d_cout1_f32(const vfx_tensor* x, const float* w, const float* bias,
+                         const vfx_tensor* y, int B, int Cin, int L, int k, int pad_mode,
+                         int post_act, int out_mask_log2, vfx_stream_t stream);
+
+/* avg_pool2d(2,2) (floor) on pitch maps: (H, P) -> (H/2, P/2).
+ * Replaces voicefixer/restorer/modules.py:103. */
+int vfx_avgpool2x2_f32(const vfx_tensor* x, const vfx_tensor* y, int B, int C, int H,
+                       int pitch_log2, vfx_stream_t stream);
+
+/* ---- analysis front-end ---------------------------------------------------------- */
+
+/* One-time upload of the tables used by vfx_stft_mel_f32: periodic hann window [2048],
+ * twiddles exp(-2*pi*i*m/2048) m<1024 as interleaved (re,im) [2048], and the banded mel
+ * filterbank: lo[128], hi[128] (inclusive bin range), off[128] (start into coef), coef[nnz].
+ * All HOST pointers; the library keeps device copies. */
+int vfx_frontend_init(const float* window, const float* twiddle, const int32_t* lo,
+                      const int32_t* hi, const int32_t* off, const float* coef, int nnz);
+
+/* wav [B][N] (row stride wav_stride) -> mel [B][T][128], T = 1 + N/441.  Reflect-padded,
+ * centred STFT (n_fft 2048, hop 441), |.| with the 1e-8 power clamp, banded HTK mel.
+ * The 1025-bin spectrogram never leaves LDS.  N >= 1025.
+ * Replaces voicefixer/base.py:78-85 (_pre): fDomainHelper.py:81-110 + mel_scale.py:63-77. */
+int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int N, float* mel,
+                     vfx_stream_t stream);
+
+/* (B,T,128) frame-major <-> channel-major (B,128,ld) transposes used around the denoiser. */
+int vfx_tm_to_cm_f32(const float* src, float* dst, int B, int T, int C, int64_t dst_bstride,
+                     int64_t dst_cstride, vfx_stream_t stream);
+
+/* clean = mask*mel; x = log10(max(clean,1e-8)); U = [log10(max(mel,1e-8)), x] written as the
+ * UNet input (B,2,Tp,128-pitch) with bin 127 and rows >= T zero.  mask is channel-major
+ * (B,128,*).  Replaces voicefixer/restorer/model.py:105-108 + model_kqq_bn.py:145-151. */
+int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, float* unet_in, int B, int T,
+                       int Tp, vfx_stream_t stream);
+
+/* logmel = unet_out + x, x = log10(max(mask*mel,1e-8)); the UNet never sees mel bin 127 and
+ * emits 0 there (model_kqq_bn.py:151,177), so logmel[...,127] = x[...,127] is recomputed from
+ * mel and mask.  denoised = 10^min(logmel,5).  Both outputs are (B,T,128) frame-major.
+ * Replaces restorer/model.py:112 + voicefixer/base.py:125 (from_log). */
+int vfx_unet_output_f32(const float* unet_out, const float* unet_in, const float* mel,
+                        const vfx_tensor* mask, float* logmel, float* denoised, int B, int T,
+                        int Tp, vfx_stream_t stream);
+
+/* 2-layer-stack building block: one bidirectional GRU layer, hidden 256, PyTorch gate order
+ * (r,z,n), h0 = 0.  gi = x-projections incl. b_ih, frame-major (B,T,1536) = [fwd r,z,n |
+ * bwd r,z,n].  whh_t = [2][256][768] (transposed W_hh per direction), bhh = [2][768].
+ * out is channel-major (B,512,*): fwd in channels 0..255, bwd in 256..511.
+ * Replaces the recurrent part of torch.nn.GRU in voicefixer/restorer/model.py:37-44,57-62. */
+int vfx_gru_bidir_f32(const float* gi, const float* whh_t, const float* bhh,
+                      const vfx_tensor* out, int B, int T, vfx_stream_t stream);
+
+/* ---- synthesis front/back -------------------------------------------------------- */
+
+/* mel (B,T,128) linear -> cond (B,128,T') channel-major, T' = T + T%2 + 4, tail = -4.0:
+ * m/=18.8927416350036*exp(0.0269863588184314*k); S=20log10(max(1e-5,|m|))-20;
+ * c=clip(8(S+115)/115-4,-4,4).  Replaces voicefixer/vocoder/base.py:51-54 +
+ * model/util.py:8-36,69-80 + config.py:310-316. */
+int vfx_mel_to_cond_f32(const float* mel, const vfx_tensor* cond, int B, int T,
+                        vfx_stream_t stream);
+
+/* Per-utterance peak rule + centre trim (voicefixer/base.py:131-135, _trim_center :63-76):
+ * peak[b] = max|y[b,:]|; out[b, 0:N] = y[b, d/2 : d/2+N] * (peak>1 ? 1/peak : 1), d = Ly-N.
+ * peak_ws is a caller-provided device buffer of B uint32 words. */
+int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
+                 int N, int B, uint32_t* peak_ws, vfx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VFX_HIP_H */

@@ -1,0 +1,366 @@
+"""Per-kernel parity: every libvfx_hip entry point (called through the C ABI via ctypes)
+against the fp32 torch-CPU statement of the same operator / the oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from voicefixer_amd import ops, packing, _lib  # noqa: E402
+from oracle import oracle  # noqa: E402  (checker only)
+
+DEV = "cuda"
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _padded(t, lpad):
+    """Device copy of (B,C,L) into a (B,C,lpad) buffer pre-filled with NaN (catches over-reads)."""
+    B, Cn, L = t.shape
+    buf = torch.full((B, Cn, lpad), float("nan"), device=DEV)
+    buf[:, :, :L] = t.to(DEV)
+    return buf
+
+
+def _close(got, want, tol):
+    got = got.cpu()
+    assert got.shape == want.shape
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    scale = want.abs().max().item() + 1e-12
+    assert err <= tol * max(1.0, scale), "max err %g (scale %g)" % (err, scale)
+
+
+def _ref_act(x, pre, slope, scale=None, shift=None):
+    if pre == _lib.PRE_LRELU:
+        return F.leaky_relu(x, slope)
+    if pre == _lib.PRE_AFFINE_LRELU:
+        shp = [1, -1] + [1] * (x.dim() - 2)
+        return F.leaky_relu(x * scale.reshape(shp) + shift.reshape(shp), slope)
+    return x
+
+
+def _ref_post(y, post, slope):
+    if post == _lib.POST_LRELU:
+        return F.leaky_relu(y, slope)
+    if post == _lib.POST_ELU:
+        return F.elu(y)
+    if post == _lib.POST_TANH:
+        return torch.tanh(y)
+    if post == _lib.POST_SIGMOID:
+        return torch.sigmoid(y)
+    if post == _lib.POST_LRELU_SNAKE:
+        u = F.leaky_relu(y, slope)
+        return u + torch.sin(u)
+    return y
+
+
+CONV1D_CASES = [
+    # B, Cin, Cout, L, k, dil, pad, pre, post, res
+    (2, 64, 64, 1000, 3, 1, 0, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (1, 64, 64, 3001, 3, 27, 0, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (2, 128, 128, 700, 3, 243, 0, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (1, 256, 256, 1500, 3, 729, 0, _lib.PRE_LRELU, _lib.POST_LRELU, True),
+    (1, 512, 512, 742, 3, 2187, 0, _lib.PRE_LRELU, _lib.POST_LRELU, False),   # dilation > L
+    (1, 128, 512, 106, 3, 1, 0, _lib.PRE_NONE, _lib.POST_ELU, False),          # condnet.0
+    (1, 512, 1024, 106, 7, 1, 1, _lib.PRE_NONE, _lib.POST_LRELU_SNAKE, False),  # pre conv, reflect
+    (3, 64, 32, 333, 3, 9, 0, _lib.PRE_NONE, _lib.POST_SIGMOID, True),
+    (2, 96, 384, 50, 1, 1, 0, _lib.PRE_NONE, _lib.POST_NONE, False),
+]
+
+
+@pytest.mark.parametrize("case", CONV1D_CASES)
+def test_conv1d(case):
+    B, Cin, Cout, L, k, dil, pad, pre, post, use_res = case
+    x = _rand((B, Cin, L), 1)
+    w = _rand((Cout, Cin, k), 2, (Cin * k) ** -0.5)
+    bias = _rand((Cout,), 3, 0.1)
+    res = _rand((B, Cout, L), 4) if use_res else None
+    xin = _ref_act(x, pre, 0.01)
+    p = (k - 1) // 2 * dil
+    if pad == 1:
+        ref = F.conv1d(F.pad(xin, (p, p), mode="reflect"), w, bias, dilation=dil)
+    else:
+        ref = F.conv1d(xin, w, bias, dilation=dil, padding=p)
+    if use_res:
+        ref = ref + res
+    ref = _ref_post(ref, post, 0.2)
+    lp = (L + 67) // 4 * 4
+    xd = _padded(x, lp)
+    yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+    rd = _padded(res, lp) if use_res else None
+    act = ops.Act(pre=pre, pre_slope=0.01, post=post, post_slope=0.2)
+    before = _lib.lib().vfx_launch_count()
+    ops.conv1d(xd, packing.pack_conv1d(w).to(DEV), bias.to(DEV), yd, L, k, dil, pad, act, rd)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1
+    _close(yd[:, :, :L], ref, 2e-5)
+    assert torch.isnan(yd[:, :, L:]).all()  # nothing written past L
+
+
+def test_linear_transposed_output():
+    """Linear as conv k=1 with a frame-major output view (B,T,out) -- used for GRU x-projections."""
+    B, T, Cin, Cout = 2, 101, 512, 1536
+    x = _rand((B, Cin, T), 5)
+    w = _rand((Cout, Cin), 6, Cin ** -0.5)
+    bias = _rand((Cout,), 7, 0.1)
+    ref = F.linear(x.transpose(1, 2), w, bias)  # (B,T,Cout)
+    xd = _padded(x, 104)
+    out = torch.full((B, T, Cout), float("nan"), device=DEV)
+    ops.conv1d(xd, packing.pack_linear(w).to(DEV), bias.to(DEV), out.transpose(1, 2), T, 1)
+    torch.cuda.synchronize()
+    _close(out, ref, 2e-5)
+
+
+@pytest.mark.parametrize("cfg", [(1, 1024, 512, 106, 7), (2, 256, 128, 531, 3), (1, 128, 64, 1000, 3),
+                                 (2, 64, 32, 37, 7)])
+def test_convtr1d(cfg):
+    B, Cin, Cout, Lin, s = cfg
+    x = _rand((B, Cin, Lin), 8)
+    w = _rand((Cin, Cout, 2 * s), 9, (2 * Cin) ** -0.5)
+    bias = _rand((Cout,), 10, 0.1)
+    ref = F.conv_transpose1d(x, w, bias, stride=s, padding=s // 2 + s % 2, output_padding=s % 2)
+    assert ref.shape[-1] == s * Lin
+    xd = _padded(x, (Lin + 7) // 4 * 4)
+    Lo = s * Lin
+    yd = torch.full((B, Cout, (Lo + 7) // 4 * 4), float("nan"), device=DEV)
+    ops.convtr1d(xd, packing.pack_convtr1d(w).to(DEV), bias.to(DEV), yd, Lin, s)
+    torch.cuda.synchronize()
+    _close(yd[:, :, :Lo], ref, 2e-5)
+    assert torch.isnan(yd[:, :, Lo:]).all()
+
+
+def _to_pitch(t, lp):
+    """(B,C,H,W=P-1) -> (B,C,H*P) with a NaN pad column (kernels must mask it on read)."""
+    B, Cn, H, W = t.shape
+    P = 1 << lp
+    assert W == P - 1
+    buf = torch.full((B, Cn, H, P), float("nan"))
+    buf[..., :W] = t
+    return buf.reshape(B, Cn, H * P)
+
+
+def _from_pitch(t, H, lp):
+    P = 1 << lp
+    return t.reshape(t.shape[0], t.shape[1], H, P)
+
+
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 64, 7, True), (1, 2, 32, 64, 7, False), (2, 64, 64, 32, 6, True),
+                                 (1, 384, 384, 4, 2, True), (1, 768, 384, 2, 1, False), (3, 128, 128, 16, 5, True)])
+def test_conv2d_3x3_bn_lrelu_residual(cfg):
+    B, Cin, Cout, H, lp, use_res = cfg
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 11)
+    w = _rand((Cout, Cin, 3, 3), 12, (Cin * 9) ** -0.5)
+    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(13))
+    shift = _rand((Cin,), 14, 0.3)
+    res = _rand((B, Cout, H, P - 1), 15) if use_res else None
+    ref = F.conv2d(_ref_act(x, _lib.PRE_AFFINE_LRELU, 0.01, scale, shift), w, padding=1)
+    if use_res:
+        ref = ref + res
+    xd = _to_pitch(x, lp).to(DEV)
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    rd = _to_pitch(res, lp).to(DEV) if use_res else None
+    if rd is not None:
+        rd = torch.nan_to_num(rd, nan=0.0)  # residual pad column is a structural zero in real use
+    act = ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=scale.to(DEV), shift=shift.to(DEV))
+    ops.conv2d(xd, packing.pack_conv2d(w).to(DEV), None, yd, H, lp, 3, act, rd)
+    torch.cuda.synchronize()
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 2e-5)
+    assert (got[..., P - 1] == 0).all()  # pad column written as zero
+
+
+def test_conv2d_1x1_bias_residual():
+    B, Cin, Cout, H, lp = 2, 64, 32, 16, 6
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 16)
+    w = _rand((Cout, Cin, 1, 1), 17, Cin ** -0.5)
+    bias = _rand((Cout,), 18, 0.1)
+    res = _rand((B, Cout, H, P - 1), 19)
+    ref = F.conv2d(x, w, bias) + res
+    xd = torch.nan_to_num(_to_pitch(x, lp), nan=0.0).to(DEV)
+    rd = torch.nan_to_num(_to_pitch(res, lp), nan=0.0).to(DEV)
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    ops.conv2d(xd, packing.pack_conv2d(w).to(DEV), bias.to(DEV), yd, H, lp, 1, None, rd)
+    torch.cuda.synchronize()
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 2e-5)
+    assert (got[..., P - 1] == 0).all()
+
+
+@pytest.mark.parametrize("cfg", [(2, 64, 32, 8, 3), (1, 384, 384, 2, 1), (1, 128, 64, 16, 5)])
+def test_convtr2d(cfg):
+    B, Cin, Cout, h, lp = cfg
+    Pi = 1 << lp
+    x = _rand((B, Cin, h, Pi - 1), 20)
+    w = _rand((Cin, Cout, 3, 3), 21, (Cin * 2.25) ** -0.5)
+    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(22))
+    shift = _rand((Cin,), 23, 0.3)
+    ref = F.conv_transpose2d(_ref_act(x, _lib.PRE_AFFINE_LRELU, 0.0, scale, shift), w, stride=2)[:, :, :-1, :]
+    assert ref.shape[2:] == (2 * h, 2 * Pi - 1)
+    xd = _to_pitch(x, lp).to(DEV)
+    # write into the first Cout channels of a concat buffer with 2*Cout channels
+    cat = torch.full((B, 2 * Cout, 2 * h * 2 * Pi), float("nan"), device=DEV)
+    act = ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.0, scale=scale.to(DEV), shift=shift.to(DEV))
+    ops.convtr2d_3x3s2(xd, packing.pack_convtr2d(w).to(DEV), cat[:, :Cout], h, lp, act)
+    torch.cuda.synchronize()
+    got = _from_pitch(cat[:, :Cout], 2 * h, lp + 1)
+    _close(got[..., : 2 * Pi - 1], ref, 2e-5)
+    assert (got[..., 2 * Pi - 1] == 0).all()
+    assert torch.isnan(cat[:, Cout:]).all()
+
+
+def test_conv_cout1_k7_reflect_tanh():
+    B, Cin, L = 2, 64, 4410
+    x = _rand((B, Cin, L), 24)
+    w = _rand((1, Cin, 7), 25, (Cin * 7) ** -0.5)
+    bias = _rand((1,), 26, 0.1)
+    ref = torch.tanh(F.conv1d(F.pad(x, (3, 3), mode="reflect"), w, bias))
+    xd = _padded(x, L + 6)
+    yd = torch.full((B, 1, L + 2), float("nan"), device=DEV)
+    ops.conv1d_cout1(xd, packing.pack_cout1(w).to(DEV), bias.to(DEV), yd, L, 7, _lib.PAD_REFLECT, _lib.POST_TANH)
+    torch.cuda.synchronize()
+    _close(yd[:, :, :L], ref, 1e-5)
+
+
+def test_conv_cout1_1x1_masked():
+    B, Cin, H, lp = 2, 32, 8, 7
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 27)
+    w = _rand((1, Cin, 1, 1), 28, Cin ** -0.5)
+    bias = _rand((1,), 29, 0.1)
+    ref = F.conv2d(x, w, bias)
+    xd = torch.nan_to_num(_to_pitch(x, lp), nan=0.0).to(DEV)
+    yd = torch.full((B, 1, H * P), float("nan"), device=DEV)
+    ops.conv1d_cout1(xd, packing.pack_cout1(w).to(DEV), bias.to(DEV), yd, H * P, 1, 0, 0, lp)
+    torch.cuda.synchronize()
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 1e-5)
+    assert (got[..., P - 1] == 0).all()
+
+
+def test_avgpool():
+    B, Cn, H, lp = 2, 5, 8, 4
+    P = 1 << lp
+    x = _rand((B, Cn, H, P - 1), 30)
+    ref = F.avg_pool2d(x, 2)
+    xd = torch.nan_to_num(_to_pitch(x, lp), nan=0.0).to(DEV)
+    yd = torch.full((B, Cn, (H // 2) * (P // 2)), float("nan"), device=DEV)
+    ops.avgpool2x2(xd, yd, H, lp)
+    torch.cuda.synchronize()
+    got = _from_pitch(yd, H // 2, lp - 1)
+    _close(got[..., : P // 2 - 1], ref, 1e-6)
+    assert (got[..., P // 2 - 1] == 0).all()
+
+
+@pytest.mark.parametrize("n", [1025, 15523, 44100])
+def test_stft_mel(n):
+    wav = _rand((2, n), 31, 0.2)
+    ref = oracle.wav_to_mel(wav)[:, 0]  # (B,T,128)
+    T = 1 + n // 441
+    wd = torch.zeros((2, n + 5), device=DEV)
+    wd[:, :n] = wav.to(DEV)
+    mel = torch.full((2, T, 128), float("nan"), device=DEV)
+    ops.stft_mel(wd, mel, n)
+    torch.cuda.synchronize()
+    got = mel.cpu()
+    assert torch.isfinite(got).all()
+    rel = (got - ref).norm() / ref.norm()
+    assert rel < 1e-5, rel.item()
+    assert (got - ref).abs().max() <= 1e-4 * ref.abs().max()
+
+
+def test_gru_bidir():
+    B, T, H = 3, 37, 256
+    x = _rand((B, T, 512), 32)
+    params = {}
+    g = torch.Generator().manual_seed(33)
+    for suf in ("", "_reverse"):
+        params["w_ih" + suf] = (torch.rand((768, 512), generator=g) * 2 - 1) / 16
+        params["w_hh" + suf] = (torch.rand((768, 256), generator=g) * 2 - 1) / 16
+        params["b_ih" + suf] = (torch.rand((768,), generator=g) * 2 - 1) / 16
+        params["b_hh" + suf] = (torch.rand((768,), generator=g) * 2 - 1) / 16
+    outs, gis = [], []
+    for suf, rev in (("", False), ("_reverse", True)):
+        outs.append(oracle._gru_dir(x, params["w_ih" + suf], params["w_hh" + suf], params["b_ih" + suf],
+                                    params["b_hh" + suf], rev))
+        gis.append(x @ params["w_ih" + suf].t() + params["b_ih" + suf])
+    ref = torch.cat(outs, -1)  # (B,T,512)
+    gi = torch.cat(gis, -1).contiguous().to(DEV)  # (B,T,1536)
+    whh_t = torch.stack([params["w_hh"].t().contiguous(), params["w_hh_reverse"].t().contiguous()]).to(DEV)
+    bhh = torch.stack([params["b_hh"], params["b_hh_reverse"]]).to(DEV)
+    out = torch.full((B, 512, 40), float("nan"), device=DEV)
+    ops.gru_bidir(gi, whh_t, bhh, out, T)
+    torch.cuda.synchronize()
+    _close(out[:, :, :T].transpose(1, 2), ref, 1e-5)
+
+
+def test_mel_to_cond():
+    g = torch.Generator().manual_seed(34)
+    for T in (101, 24):
+        mel = 10 ** (torch.rand((2, 1, T, 128), generator=g) * 6 - 3)
+        mel[0, 0, :2, :7] = 0.0
+        ref = oracle.mel_to_cond(mel)
+        Tc = T + T % 2 + 4
+        cond = torch.full((2, 128, Tc + 3), float("nan"), device=DEV)
+        ops.mel_to_cond(mel[:, 0].contiguous().to(DEV), cond, T)
+        torch.cuda.synchronize()
+        _close(cond[:, :, :Tc], ref, 2e-5)
+
+
+def test_unet_input_output_and_post():
+    B, T, Tp = 2, 36, 64
+    g = torch.Generator().manual_seed(35)
+    mel = 10 ** (torch.rand((B, 1, T, 128), generator=g) * 4 - 2)
+    mask = torch.rand((B, 1, T, 128), generator=g)
+    x = oracle.to_log(mask * mel)
+    u_ref = torch.cat([oracle.to_log(mel), x], dim=1)
+    mel_d = mel[:, 0].contiguous().to(DEV)
+    mask_cm = torch.zeros((B, 128, 40), device=DEV)
+    mask_cm[:, :, :T] = mask[:, 0].transpose(1, 2).to(DEV)
+    u = torch.full((B, 2, Tp, 128), float("nan"), device=DEV)
+    ops.unet_input(mel_d, mask_cm, u, T, Tp)
+    torch.cuda.synchronize()
+    got = u.cpu()
+    _close(got[:, :, :T, :127], u_ref[..., :127], 1e-6)
+    assert (got[:, :, T:, :] == 0).all() and (got[..., 127] == 0).all()
+
+    uo = _rand((B, 1, Tp, 128), 36)
+    uo[..., 127] = 0
+    logmel = torch.empty((B, T, 128), device=DEV)
+    den = torch.empty((B, T, 128), device=DEV)
+    ops.unet_output(uo.to(DEV), u, mel_d, mask_cm, logmel, den, T, Tp)
+    torch.cuda.synchronize()
+    ref_lm = uo[:, 0, :T] + x[:, 0]
+    _close(logmel, ref_lm, 1e-5)
+    _close(den, oracle.from_log(ref_lm), 1e-5)
+
+    # peak rule + centre trim
+    Ly, N = 441 * 40, 15523
+    y = _rand((B, Ly), 37, 0.2)
+    y[1] *= 8.0  # second utterance exceeds 1.0 -> normalised by its own peak only
+    yd = y.to(DEV)
+    out = torch.empty((B, N), device=DEV)
+    ws = torch.zeros(B, dtype=torch.int32, device=DEV)
+    ops.post(yd, Ly, out, N, ws)
+    torch.cuda.synchronize()
+    for b in range(B):
+        e = y[b][None, None]
+        pk = e.abs().max()
+        if pk > 1:
+            e = e / pk
+        _close(out[b], oracle.trim_center(e, N)[0, 0], 1e-6)
+
+
+def test_bad_arguments_fail_loudly():
+    x = torch.zeros((1, 64, 100), device=DEV)
+    w = torch.zeros((3, 64, 48), device=DEV)  # Cout = 48 not a multiple of 32
+    with pytest.raises(_lib.VfxError):
+        ops.conv1d(x, w, None, torch.zeros((1, 48, 100), device=DEV), 100, 3)
+    with pytest.raises(_lib.VfxError):
+        ops.conv1d(torch.zeros((1, 64, 100)), w, None, x, 100, 3)  # CPU tensor

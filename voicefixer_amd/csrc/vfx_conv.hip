@@ -1,0 +1,565 @@
+// vfx_conv.hip -- the convolution family of the VoiceFixer path as ONE implicit-GEMM
+// kernel on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak on MI355X).
+//
+// Every convolution on the path (dilated Conv1d k3, reflect-padded Conv1d k7,
+// polyphase ConvTranspose1d, Conv2d 3x3/1x1 on pitch maps, ConvTranspose2d 3x3 s2,
+// Linear) is a sum over "taps": for output channel n and logical position q
+//     acc[n, q] = sum_t sum_c  W[slab_t][c][n] * pre(X[c][q + off_t])
+// so the GEMM is  M = Cout (MFMA rows, A = packed weights, n contiguous),
+//                 N = positions (MFMA cols, B = activations, l contiguous),
+//                 K = Cin x taps.
+// No im2col is materialised: an activation tile WITH its halo is staged once per K-chunk
+// into LDS and each tap reads it at a shifted column (large dilations use one segment per
+// tap instead).  The pre-activation (leaky-ReLU / eval-BatchNorm+ReLU), zero/reflect
+// padding and the pad-column mask of 2-D maps are applied while staging; bias, residual,
+// activation and the output index map (stride-s interleave of transposed convolutions)
+// in the epilogue.
+//
+// Workgroup = 256 threads = 4 wave64, each wave owns RM x RL accumulators of 32x32
+// (16 VGPR each).  LDS is double buffered, the next K-chunk travels global -> VGPR while
+// the MFMAs of the current one run, one barrier per chunk; <= 80 KB LDS and <= 256 VGPR
+// keep two workgroups per CU so one stages while the other computes.
+#include "vfx_common.h"
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+
+#define VFX_MAXPH 8
+#define VFX_MAXT 9
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// per-phase tap tables live in device memory (cached per distinct conv geometry): a by-value
+// kernarg array indexed per lane makes the compiler hold the whole table in SGPRs.
+struct PhaseTab {
+    int ntaps, nseg, ooff, pad_;
+    int seg_org[VFX_MAXT];  // global origin of segment s relative to q0 (multiple of 4)
+    int tap_lds[VFX_MAXT];  // LDS float offset of (tap t, row 0, q-local 0)
+    int tap_w[VFX_MAXT];    // weight slab of tap t
+};
+struct ConvTables {
+    PhaseTab ph[VFX_MAXPH];
+};
+
+struct ConvArgs {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* res;
+    float* y;
+    const float* pre_scale;
+    const float* pre_shift;
+    const ConvTables* tab;
+    int B, Cin, CinPad, Cout, Lin, Lq, Lout;
+    long long x_bs, x_cs, y_bs, y_cs, y_ls, r_bs, r_cs, r_ls;
+    int segw;       // LDS row pitch of the activation tile (floats, multiple of 4)
+    int xs_floats;  // LDS floats reserved for the activation tile (per buffer)
+    int ws_floats;  // LDS floats reserved for the weight tile (per buffer)
+    int q_shift, q_mask, o_rs, o_cs;  // out = (q >> q_shift)*o_rs + (q & q_mask)*o_cs + ooff
+    int pad_mode, pre_act, post_act;
+    float pre_slope, post_slope;
+    int in_mask, out_mask;  // pitch-1 (e.g. 127) or 0: positions with (l & mask) == mask are structural zeros
+};
+
+template <int KC>
+struct StageCfg {
+    static constexpr int MAXXV = 7;  // float4 per thread for the activation tile
+    static constexpr int MAXWV = 5;  // float4 per thread for the weight tile
+};
+
+template <int BM, int BL, int WGM, int WGL, int KC>
+__global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
+    constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
+    constexpr int MAXXV = StageCfg<KC>::MAXXV, MAXWV = StageCfg<KC>::MAXWV;
+    static_assert(WGM * WGL == 4 && RM >= 1 && RL >= 1, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wm = wave / WGL, wl = wave % WGL;
+    const int q0 = blockIdx.x * BL;
+    const int m0g = blockIdx.y * BM;
+    const int ph = m0g / a.Cout;
+    const int m0 = m0g - ph * a.Cout;
+    const int b = blockIdx.z;
+    const PhaseTab* __restrict__ pt = &a.tab->ph[ph];
+    // block-uniform table entries: readfirstlane makes the uniformity provable (SGPRs, scalar branches)
+    const int nt = __builtin_amdgcn_readfirstlane(pt->ntaps);
+    const int nseg = __builtin_amdgcn_readfirstlane(pt->nseg);
+    int tap_lds[VFX_MAXT];
+#pragma unroll
+    for (int t = 0; t < VFX_MAXT; ++t) tap_lds[t] = __builtin_amdgcn_readfirstlane(pt->tap_lds[t]);
+    const int segw = a.segw;
+    const int sv = segw >> 2;                 // float4 per LDS row
+    const int xtotal = nseg * KC * sv;        // float4 in the activation tile
+    const int wtotal = nt * KC * (BM / 4);    // float4 in the weight tile
+    const int bufstride = a.xs_floats + a.ws_floats;
+
+    const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
+    const int xcs = (int)a.x_cs;
+
+    // ---- per-thread staging slots (fixed for the whole K loop) ----------------------
+    int x_l[MAXXV];    // global l of element 0 of the vector (multiple of 4, may be < 0)
+    int x_kc[MAXXV];   // row (channel within chunk), -1 = slot unused
+#pragma unroll
+    for (int j = 0; j < MAXXV; ++j) {
+        const int i = tid + 256 * j;
+        x_kc[j] = -1;
+        x_l[j] = 0;
+        if (i < xtotal) {
+            const int s = i / (KC * sv);
+            const int rem = i - s * (KC * sv);
+            const int kc = rem / sv;
+            const int v = rem - kc * sv;
+            x_kc[j] = kc;
+            x_l[j] = q0 + pt->seg_org[s] + 4 * v;
+        }
+    }
+    int w_off[MAXWV];  // element offset into w for chunk 0, -1 = unused
+#pragma unroll
+    for (int j = 0; j < MAXWV; ++j) {
+        const int i = tid + 256 * j;
+        w_off[j] = -1;
+        if (i < wtotal) {
+            const int t = i / (KC * (BM / 4));
+            const int rem = i - t * (KC * (BM / 4));
+            const int kc = rem / (BM / 4);
+            const int v = rem - kc * (BM / 4);
+            w_off[j] = (pt->tap_w[t] * a.CinPad + kc) * a.Cout + m0 + 4 * v;
+        }
+    }
+
+    float4 xv[MAXXV];
+    float4 wv[MAXWV];
+    const int Lin = a.Lin;
+    const bool reflect = a.pad_mode == VFX_PAD_REFLECT;
+
+    auto stage_load = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < MAXXV; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int kc = x_kc[j];
+            if (kc >= 0 && c0 + kc < a.Cin) {
+                const float* row = xb + (long long)(c0 + kc) * xcs;
+                const int l = x_l[j];
+                if (l >= 0 && l + 3 < Lin) {
+                    v = *reinterpret_cast<const float4*>(row + l);
+                } else {
+                    float e[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        int g = l + k;
+                        if (reflect) {
+                            if (g < 0) g = -g;
+                            if (g >= Lin) g = 2 * (Lin - 1) - g;
+                        }
+                        e[k] = (g >= 0 && g < Lin) ? row[g] : 0.f;
+                    }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            xv[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < MAXWV; ++j) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (w_off[j] >= 0) v = *reinterpret_cast<const float4*>(a.w + w_off[j] + (long long)c0 * a.Cout);
+            wv[j] = v;
+        }
+    };
+
+    auto stage_write = [&](int c0, float* xs, float* ws) {
+#pragma unroll
+        for (int j = 0; j < MAXXV; ++j) {
+            const int kc = x_kc[j];
+            if (kc < 0) continue;
+            float e[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
+            const int l = x_l[j];
+            if (a.pre_act != VFX_PRE_NONE) {
+                float sc = 1.f, sh = 0.f;
+                const int c = c0 + kc;
+                if (a.pre_act == VFX_PRE_AFFINE_LRELU && c < a.Cin) {
+                    sc = a.pre_scale[c];
+                    sh = a.pre_shift[c];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] = vfx_lrelu(e[k] * sc + sh, a.pre_slope);
+                // zero padding applies to the ACTIVATED input
+                if (!reflect && (l < 0 || l + 3 >= Lin || c >= a.Cin)) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (l + k < 0 || l + k >= Lin || c >= a.Cin) e[k] = 0.f;
+                }
+            }
+            if (a.in_mask) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (((l + k) & a.in_mask) == a.in_mask) e[k] = 0.f;
+            }
+            *reinterpret_cast<float4*>(xs + 4 * (tid + 256 * j)) = make_float4(e[0], e[1], e[2], e[3]);
+        }
+#pragma unroll
+        for (int j = 0; j < MAXWV; ++j)
+            if (w_off[j] >= 0) *reinterpret_cast<float4*>(ws + 4 * (tid + 256 * j)) = wv[j];
+    };
+
+    f32x16 acc[RM][RL];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int a_col = wm * WMT + lo;  // column into the weight tile row
+    const int b_col = wl * WLT + lo;  // column into the activation tile row
+
+    stage_load(0);
+    stage_write(0, smem, smem + a.xs_floats);
+    __syncthreads();
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* xs = smem + (ch & 1) * bufstride;
+        const float* ws = xs + a.xs_floats;
+        if (ch + 1 < nchunks) stage_load((ch + 1) * KC);
+
+#pragma unroll
+        for (int t = 0; t < VFX_MAXT; ++t) {
+            if (t < nt) {
+                const float* xt = xs + tap_lds[t] + b_col;
+                const float* wt = ws + t * (KC * BM) + a_col;
+#pragma unroll
+                for (int kk = 0; kk < KC / 2; ++kk) {
+                    float af[RM], bf[RL];
+#pragma unroll
+                    for (int i = 0; i < RM; ++i) af[i] = wt[(2 * kk + hi) * BM + i * 32];
+#pragma unroll
+                    for (int j = 0; j < RL; ++j) bf[j] = xt[(2 * kk + hi) * segw + j * 32];
+#pragma unroll
+                    for (int i = 0; i < RM; ++i)
+#pragma unroll
+                        for (int j = 0; j < RL; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+
+        if (ch + 1 < nchunks) {
+            float* nxs = smem + ((ch + 1) & 1) * bufstride;
+            stage_write((ch + 1) * KC, nxs, nxs + a.xs_floats);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float* __restrict__ yb = a.y + (long long)b * a.y_bs;
+    const float* __restrict__ rb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
+    const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        const int q = q0 + wl * WLT + j * 32 + lo;
+        const int out = (q >> a.q_shift) * a.o_rs + (q & a.q_mask) * a.o_cs + ooff;
+        const bool ok = q < a.Lq && out >= 0 && out < a.Lout;
+        const bool zero = a.out_mask && ((out & a.out_mask) == a.out_mask);
+#pragma unroll
+        for (int i = 0; i < RM; ++i) {
+            // rolled over the 16 accumulator registers (uniform dynamic index -> v_movrel),
+            // so the activation code is emitted RM*RL times instead of 16*RM*RL times
+#pragma unroll 1
+            for (int r = 0; r < 16; ++r) {
+                const int n = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (ok) {
+                    float v = acc[i][j][r];
+                    if (a.bias) v += a.bias[n];
+                    if (rb) v += rb[(long long)n * a.r_cs + (long long)out * a.r_ls];
+                    v = vfx_post(v, a.post_act, a.post_slope);
+                    if (zero) v = 0.f;
+                    yb[(long long)n * a.y_cs + (long long)out * a.y_ls] = v;
+                }
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// host side: tap tables, tile choice, launch
+// --------------------------------------------------------------------------------------
+struct TapSpec {
+    int off;
+    int slab;
+};
+struct PhaseSpec {
+    int ntaps;
+    TapSpec taps[VFX_MAXT];
+    int ooff;
+};
+
+struct TileCfg {
+    int BM, BL;
+    float util;
+};
+static const TileCfg kTiles[] = {
+    {128, 128, 1.00f}, {64, 256, 1.00f}, {128, 64, 0.90f},
+    {32, 256, 0.90f},  {64, 64, 0.75f},  {32, 128, 0.75f},
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+// Device-resident copies of tap tables, one per distinct geometry (a few dozen per model).
+// First use of a geometry does a synchronous hipMalloc+hipMemcpy (warm-up); afterwards the
+// lookup is a host-side map hit, so steady-state launches stay asynchronous/capturable.
+static const ConvTables* device_tables(const ConvTables& tb) {
+    static std::mutex mu;
+    static std::map<std::string, const ConvTables*> cache;
+    std::string key(reinterpret_cast<const char*>(&tb), sizeof(tb));
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    ConvTables* d = nullptr;
+    if (hipMalloc((void**)&d, sizeof(ConvTables)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, &tb, sizeof(ConvTables), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    cache.emplace(std::move(key), d);
+    return d;
+}
+
+static inline int floor4(int v) { return v >= 0 ? (v & ~3) : -(((-v) + 3) & ~3); }
+
+template <int BM, int BL, int WGM, int WGL, int KC>
+static int launch_cfg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}
+
+static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpec* phs, int BL, int KC) {
+    // decide halo vs per-tap segments per phase; compute LDS pitch and offsets
+    int segw = 0;
+    bool halo[VFX_MAXPH];
+    for (int p = 0; p < nphase; ++p) {
+        int mn = phs[p].taps[0].off, mx = mn;
+        for (int t = 1; t < phs[p].ntaps; ++t) {
+            mn = phs[p].taps[t].off < mn ? phs[p].taps[t].off : mn;
+            mx = phs[p].taps[t].off > mx ? phs[p].taps[t].off : mx;
+        }
+        const int span = mx - mn;
+        halo[p] = (long long)BL + span + 3 <= (long long)phs[p].ntaps * (BL + 3);
+        int need;
+        if (halo[p]) {
+            need = (mn - floor4(mn)) + BL + span;
+        } else {
+            need = BL + 3;
+        }
+        need = (need + 3) & ~3;
+        segw = need > segw ? need : segw;
+    }
+    a.segw = segw;
+    int xs = 0;
+    for (int p = 0; p < nphase; ++p) {
+        PhaseTab& T = tb.ph[p];
+        T.ntaps = phs[p].ntaps;
+        T.ooff = phs[p].ooff;
+        if (halo[p]) {
+            int mn = phs[p].taps[0].off;
+            for (int t = 1; t < phs[p].ntaps; ++t) mn = phs[p].taps[t].off < mn ? phs[p].taps[t].off : mn;
+            const int org = floor4(mn);
+            T.nseg = 1;
+            T.seg_org[0] = org;
+            for (int t = 0; t < phs[p].ntaps; ++t) {
+                T.tap_lds[t] = phs[p].taps[t].off - org;
+                T.tap_w[t] = phs[p].taps[t].slab;
+            }
+        } else {
+            T.nseg = phs[p].ntaps;
+            for (int t = 0; t < phs[p].ntaps; ++t) {
+                const int org = floor4(phs[p].taps[t].off);
+                T.seg_org[t] = org;
+                T.tap_lds[t] = t * KC * segw + (phs[p].taps[t].off - org);
+                T.tap_w[t] = phs[p].taps[t].slab;
+            }
+        }
+        const int fl = T.nseg * KC * segw;
+        xs = fl > xs ? fl : xs;
+    }
+    a.xs_floats = xs;
+    return VFX_OK;
+}
+
+static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, const vfx_tensor* res,
+                       const vfx_tensor* y, int B, int Cin, int Cout, int Lin, int Lq, int Lout,
+                       int nphase, const PhaseSpec* phs, int q_shift, int q_mask, int o_rs, int o_cs,
+                       int pad_mode, const vfx_act* act, int in_mask, int out_mask, hipStream_t stream) {
+    if (!x || !y || !w || !x->ptr || !y->ptr || B <= 0 || Cin <= 0 || Cout <= 0 || Lin <= 0 || Lq <= 0)
+        return VFX_EINVAL;
+    if (Cout % 32 != 0 || nphase < 1 || nphase > VFX_MAXPH) return VFX_EINVAL;
+    if (x->lstride != 1 || (x->cstride & 3) || (x->bstride & 3) || !vfx_aligned16(x->ptr) || !vfx_aligned16(w))
+        return VFX_EALIGN;
+    if (pad_mode == VFX_PAD_REFLECT && Lin < 8) return VFX_EINVAL;
+    if (B > 65535) return VFX_EINVAL;
+
+    ConvArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = (const float*)x->ptr;
+    a.w = w;
+    a.bias = bias;
+    a.res = res ? (const float*)res->ptr : nullptr;
+    a.y = (float*)y->ptr;
+    a.B = B; a.Cin = Cin; a.CinPad = (Cin + 7) & ~7; a.Cout = Cout;
+    a.Lin = Lin; a.Lq = Lq; a.Lout = Lout;
+    a.x_bs = x->bstride; a.x_cs = x->cstride;
+    a.y_bs = y->bstride; a.y_cs = y->cstride; a.y_ls = y->lstride;
+    if (res) { a.r_bs = res->bstride; a.r_cs = res->cstride; a.r_ls = res->lstride; }
+    a.q_shift = q_shift; a.q_mask = q_mask; a.o_rs = o_rs; a.o_cs = o_cs;
+    a.pad_mode = pad_mode;
+    a.pre_act = act ? act->pre_act : VFX_PRE_NONE;
+    a.pre_slope = act ? act->pre_slope : 0.f;
+    a.pre_scale = act ? act->pre_scale : nullptr;
+    a.pre_shift = act ? act->pre_shift : nullptr;
+    a.post_act = act ? act->post_act : VFX_POST_NONE;
+    a.post_slope = act ? act->post_slope : 0.f;
+    if (a.pre_act == VFX_PRE_AFFINE_LRELU && (!a.pre_scale || !a.pre_shift)) return VFX_EINVAL;
+    a.in_mask = in_mask; a.out_mask = out_mask;
+
+    int maxnt = 0;
+    for (int p = 0; p < nphase; ++p) maxnt = phs[p].ntaps > maxnt ? phs[p].ntaps : maxnt;
+    if (maxnt < 1 || maxnt > VFX_MAXT) return VFX_EINVAL;
+    const int KC = maxnt <= 4 ? 8 : 4;
+
+    // tile choice: maximise (tile efficiency) x (tail efficiency along L) x (wave quantisation)
+    int best = -1;
+    float best_score = -1.f;
+    for (int i = 0; i < kNumTiles; ++i) {
+        const TileCfg& t = kTiles[i];
+        if (Cout % t.BM) continue;
+        if ((long long)maxnt * KC * t.BM > 5 * 1024) continue;
+        const long long lt = (Lq + t.BL - 1) / t.BL;
+        const long long nwg = lt * (long long)(nphase * Cout / t.BM) * B;
+        const float tail = (float)Lq / (float)(lt * t.BL);
+        const long long slots = 512;  // 2 workgroups per CU x 256 CUs
+        const float quant = (float)nwg / (float)(((nwg + slots - 1) / slots) * slots);
+        const float score = t.util * tail * quant;
+        if (score > best_score * 1.02f) { best_score = score; best = i; }
+    }
+    if (best < 0) return VFX_EINVAL;
+    const TileCfg& tc = kTiles[best];
+
+    ConvTables tb;
+    std::memset(&tb, 0, sizeof(tb));
+    int rc = fill_segments(a, tb, nphase, phs, tc.BL, KC);
+    if (rc) return rc;
+    int maxseg = 0;
+    for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
+    a.tab = device_tables(tb);
+    if (!a.tab) return VFX_EINVAL;
+    if ((long long)maxseg * KC * (a.segw / 4) > 7 * 256) return VFX_ERANGE;
+    a.ws_floats = maxnt * KC * tc.BM;
+    const size_t lds = 2ull * (a.xs_floats + a.ws_floats) * sizeof(float);
+    if (lds > 160 * 1024) return VFX_ERANGE;
+
+    dim3 grid((Lq + tc.BL - 1) / tc.BL, nphase * Cout / tc.BM, B);
+#define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                    \
+    if (tc.BM == BM_ && tc.BL == BL_)                                                     \
+        return KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, grid, lds, stream)        \
+                       : launch_cfg<BM_, BL_, WGM_, WGL_, 4>(a, grid, lds, stream);
+    VFX_CASE(128, 128, 2, 2)
+    VFX_CASE(64, 256, 1, 4)
+    VFX_CASE(128, 64, 4, 1)
+    VFX_CASE(32, 256, 1, 4)
+    VFX_CASE(64, 64, 2, 2)
+    VFX_CASE(32, 128, 1, 4)
+#undef VFX_CASE
+    return VFX_EINVAL;
+}
+
+// --------------------------------------------------------------------------------------
+// C ABI
+// --------------------------------------------------------------------------------------
+extern "C" int vfx_conv1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
+                              const vfx_tensor* res, const vfx_tensor* y, int B, int Cin, int Cout,
+                              int L, int k, int dilation, int pad_mode, const vfx_act* act,
+                              vfx_stream_t stream) {
+    if (k < 1 || k > VFX_MAXT || !(k & 1) || dilation < 1) return VFX_EINVAL;
+    PhaseSpec ph;
+    ph.ntaps = k;
+    ph.ooff = 0;
+    for (int t = 0; t < k; ++t) {
+        ph.taps[t].off = (t - (k - 1) / 2) * dilation;
+        ph.taps[t].slab = t;
+    }
+    return launch_conv(x, w_packed, bias, res, y, B, Cin, Cout, L, L, L, 1, &ph, 31, 0x7fffffff, 0, 1,
+                       pad_mode, act, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int vfx_convtr1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
+                                const vfx_tensor* y, int B, int Cin, int Cout, int Lin, int stride,
+                                const vfx_act* act, vfx_stream_t stream) {
+    // out[o] = x[q]*w[r] + x[q-1]*w[r+s],  u = o + pad = q*s + r   
+    if (stride < 1 || stride > VFX_MAXPH) return VFX_EINVAL;
+    const int pad = stride / 2 + stride % 2;
+    PhaseSpec ph[VFX_MAXPH];
+    for (int r = 0; r < stride; ++r) {
+        ph[r].ntaps = 2;
+        ph[r].taps[0].off = 0;
+        ph[r].taps[0].slab = r;
+        ph[r].taps[1].off = -1;
+        ph[r].taps[1].slab = r + stride;
+        ph[r].ooff = r - pad;
+    }
+    return launch_conv(x, w_packed, bias, nullptr, y, B, Cin, Cout, Lin, Lin + 1, stride * Lin, stride, ph,
+                       31, 0x7fffffff, 0, stride, VFX_PAD_ZERO, act, 0, 0, (hipStream_t)stream);
+}
+
+extern "C" int vfx_conv2d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
+                              const vfx_tensor* res, const vfx_tensor* y, int B, int Cin, int Cout, int H,
+                              int pitch_log2, int ksize, const vfx_act* act, vfx_stream_t stream) {
+    if ((ksize != 1 && ksize != 3) || pitch_log2 < 1 || pitch_log2 > 12 || H < 1) return VFX_EINVAL;
+    const int P = 1 << pitch_log2;
+    PhaseSpec ph;
+    ph.ooff = 0;
+    ph.ntaps = ksize * ksize;
+    for (int ky = 0; ky < ksize; ++ky)
+        for (int kx = 0; kx < ksize; ++kx) {
+            ph.taps[ky * ksize + kx].off = (ky - ksize / 2) * P + (kx - ksize / 2);
+            ph.taps[ky * ksize + kx].slab = ky * ksize + kx;
+        }
+    const int L = H * P;
+    return launch_conv(x, w_packed, bias, res, y, B, Cin, Cout, L, L, L, 1, &ph, 31, 0x7fffffff, 0, 1,
+                       VFX_PAD_ZERO, act, P - 1, P - 1, (hipStream_t)stream);
+}
+
+extern "C" int vfx_convtr2d_3x3s2_f32(const vfx_tensor* x, const float* w_packed, const vfx_tensor* y, int B,
+                                      int Cin, int Cout, int h, int in_pitch_log2, const vfx_act* act,
+                                      vfx_stream_t stream) {
+    // oy = 2a + py, ox = 2b + px; even parity has taps k=0 (i = a) and k=2 (i = a-1), odd has k=1.
+    if (in_pitch_log2 < 1 || in_pitch_log2 > 11 || h < 1) return VFX_EINVAL;
+    const int Pi = 1 << in_pitch_log2, Po = 2 * Pi;
+    PhaseSpec ph[4];
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            PhaseSpec& p = ph[py * 2 + px];
+            p.ntaps = 0;
+            p.ooff = py * Po + px;
+            const int nky = py == 0 ? 2 : 1, nkx = px == 0 ? 2 : 1;
+            for (int iy = 0; iy < nky; ++iy)
+                for (int ix = 0; ix < nkx; ++ix) {
+                    const int ky = py == 0 ? 2 * iy : 1, kx = px == 0 ? 2 * ix : 1;
+                    const int dy = py == 0 ? iy : 0, dx = px == 0 ? ix : 0;  // input shift (a-dy, b-dx)
+                    p.taps[p.ntaps].off = -(dy * Pi + dx);
+                    p.taps[p.ntaps].slab = ky * 3 + kx;
+                    ++p.ntaps;
+                }
+        }
+    const int Lin = h * Pi;
+    // q = a*Pi + b  ->  out = a*(2*Po) + b*2 + ooff
+    return launch_conv(x, w_packed, nullptr, nullptr, y, B, Cin, Cout, Lin, Lin, 2 * h * Po, 4, ph,
+                       in_pitch_log2, Pi - 1, 2 * Po, 2, VFX_PAD_ZERO, act, Pi - 1, Po - 1,
+                       (hipStream_t)stream);
+}

@@ -1,0 +1,190 @@
+"""Thin Python launchers for the libvfx_hip C ABI.
+
+torch is used here only as the owner of device memory and of the current HIP stream:
+every function takes CUDA(=HIP) tensors, fills ``vfx_tensor`` descriptors from their
+strides and calls the C entry point on ``torch.cuda.current_stream()``.  No torch
+arithmetic happens on this path.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (vfx_tensor, vfx_act, check, PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU, POST_NONE,
+                   POST_LRELU, POST_ELU, POST_TANH, POST_SIGMOID, POST_LRELU_SNAKE, PAD_ZERO,
+                   PAD_REFLECT)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VfxError("libvfx_hip operates on device tensors only (got a CPU tensor)")
+
+
+def tdesc(t):
+    """vfx_tensor for a (B, C, L) tensor view (any strides; element units)."""
+    assert t.dim() == 3 and t.dtype == torch.float32
+    return vfx_tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Act:
+    """Bundles the fused pre/post activation of a conv launch (keeps tensors alive)."""
+
+    def __init__(self, pre=PRE_NONE, pre_slope=0.0, scale=None, shift=None, post=POST_NONE,
+                 post_slope=0.0):
+        self.scale, self.shift = scale, shift
+        self.c = vfx_act(pre, float(pre_slope), scale.data_ptr() if scale is not None else None,
+                         shift.data_ptr() if shift is not None else None, post, float(post_slope))
+
+
+_NOACT = None
+
+
+def _act(a):
+    global _NOACT
+    if a is None:
+        if _NOACT is None:
+            _NOACT = Act()
+        a = _NOACT
+    return C.byref(a.c)
+
+
+def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None):
+    """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout]."""
+    _need_cuda(x, w, y, res, bias)
+    B = x.shape[0]
+    cin = x.shape[1] if cin is None else cin
+    cout = w.shape[2]
+    xd, yd = tdesc(x), tdesc(y)
+    rd = tdesc(res) if res is not None else None
+    rc = _lib.lib().vfx_conv1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
+                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act), _stream())
+    check(rc, "vfx_conv1d_f32")
+
+
+def convtr1d(x, w, bias, y, Lin, stride, act=None):
+    _need_cuda(x, w, y, bias)
+    B, cin = x.shape[0], x.shape[1]
+    cout = w.shape[2]
+    xd, yd = tdesc(x), tdesc(y)
+    rc = _lib.lib().vfx_convtr1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(yd), B, cin, cout, Lin, stride,
+                                     _act(act), _stream())
+    check(rc, "vfx_convtr1d_f32")
+
+
+def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None):
+    """x (B,Cin,H*P) pitch map -> y (B,Cout,H*P)."""
+    _need_cuda(x, w, y, res, bias)
+    B = x.shape[0]
+    cin = x.shape[1] if cin is None else cin
+    cout = w.shape[2]
+    xd, yd = tdesc(x), tdesc(y)
+    rd = tdesc(res) if res is not None else None
+    rc = _lib.lib().vfx_conv2d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
+                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act), _stream())
+    check(rc, "vfx_conv2d_f32")
+
+
+def convtr2d_3x3s2(x, w, y, h, in_pitch_log2, act=None):
+    _need_cuda(x, w, y)
+    B, cin = x.shape[0], x.shape[1]
+    cout = w.shape[2]
+    xd, yd = tdesc(x), tdesc(y)
+    rc = _lib.lib().vfx_convtr2d_3x3s2_f32(C.byref(xd), _ptr(w), C.byref(yd), B, cin, cout, h, in_pitch_log2,
+                                           _act(act), _stream())
+    check(rc, "vfx_convtr2d_3x3s2_f32")
+
+
+def conv1d_cout1(x, w, bias, y, L, k, pad_mode=PAD_ZERO, post=POST_NONE, out_mask_log2=0):
+    _need_cuda(x, w, y, bias)
+    B, cin = x.shape[0], x.shape[1]
+    xd, yd = tdesc(x), tdesc(y)
+    rc = _lib.lib().vfx_conv1d_cout1_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(yd), B, cin, L, k, pad_mode,
+                                         post, out_mask_log2, _stream())
+    check(rc, "vfx_conv1d_cout1_f32")
+
+
+def avgpool2x2(x, y, H, pitch_log2):
+    _need_cuda(x, y)
+    B, Cn = x.shape[0], x.shape[1]
+    xd, yd = tdesc(x), tdesc(y)
+    check(_lib.lib().vfx_avgpool2x2_f32(C.byref(xd), C.byref(yd), B, Cn, H, pitch_log2, _stream()),
+          "vfx_avgpool2x2_f32")
+
+
+_frontend_ready = False
+
+
+def frontend_init():
+    """Upload window / twiddles / banded HTK filterbank (voicefixer/tools/mel_scale.py:147-238
+    restated in float32 torch with the same op order, so the support set is bit-identical)."""
+    global _frontend_ready
+    if _frontend_ready:
+        return
+    import math
+    from .frontend_tables import tables
+    win, tw, lo, hi, off, coef = tables()
+    check(_lib.lib().vfx_frontend_init(win.ctypes.data, tw.ctypes.data, lo.ctypes.data, hi.ctypes.data,
+                                       off.ctypes.data, coef.ctypes.data, int(coef.shape[0])),
+          "vfx_frontend_init")
+    _frontend_ready = True
+
+
+def stft_mel(wav, mel, N):
+    """wav (B, >=N) device float32 -> mel (B, T, 128)."""
+    _need_cuda(wav, mel)
+    frontend_init()
+    assert wav.stride(1) == 1 and mel.is_contiguous()
+    check(_lib.lib().vfx_stft_mel_f32(_ptr(wav), wav.stride(0), wav.shape[0], N, _ptr(mel), _stream()),
+          "vfx_stft_mel_f32")
+
+
+def tm_to_cm(src, dst, T, Cn):
+    """src (B,T,C) contiguous -> dst (B,C,>=T) view."""
+    _need_cuda(src, dst)
+    assert src.is_contiguous() and dst.stride(2) == 1
+    check(_lib.lib().vfx_tm_to_cm_f32(_ptr(src), _ptr(dst), src.shape[0], T, Cn, dst.stride(0), dst.stride(1),
+                                      _stream()), "vfx_tm_to_cm_f32")
+
+
+def unet_input(mel, mask, unet_in, T, Tp):
+    _need_cuda(mel, mask, unet_in)
+    md = tdesc(mask)
+    check(_lib.lib().vfx_unet_input_f32(_ptr(mel), C.byref(md), _ptr(unet_in), mel.shape[0], T, Tp, _stream()),
+          "vfx_unet_input_f32")
+
+
+def unet_output(unet_out, unet_in, mel, mask, logmel, denoised, T, Tp):
+    _need_cuda(unet_out, unet_in, mel, mask, logmel, denoised)
+    md = tdesc(mask)
+    check(_lib.lib().vfx_unet_output_f32(_ptr(unet_out), _ptr(unet_in), _ptr(mel), C.byref(md), _ptr(logmel),
+                                         _ptr(denoised), mel.shape[0], T, Tp, _stream()), "vfx_unet_output_f32")
+
+
+def gru_bidir(gi, whh_t, bhh, out, T):
+    _need_cuda(gi, whh_t, bhh, out)
+    od = tdesc(out)
+    check(_lib.lib().vfx_gru_bidir_f32(_ptr(gi), _ptr(whh_t), _ptr(bhh), C.byref(od), gi.shape[0], T, _stream()),
+          "vfx_gru_bidir_f32")
+
+
+def mel_to_cond(mel, cond, T):
+    _need_cuda(mel, cond)
+    assert mel.is_contiguous()
+    cd = tdesc(cond)
+    check(_lib.lib().vfx_mel_to_cond_f32(_ptr(mel), C.byref(cd), mel.shape[0], T, _stream()), "vfx_mel_to_cond_f32")
+
+
+def post(y, Ly, out, N, peak_ws):
+    """y (B, >=Ly) -> out (B, N): per-utterance peak rule + centre trim."""
+    _need_cuda(y, out, peak_ws)
+    check(_lib.lib().vfx_post_f32(_ptr(y), y.stride(0), Ly, _ptr(out), out.stride(0), N, y.shape[0],
+                                  _ptr(peak_ws), _stream()), "vfx_post_f32")
