@@ -1,0 +1,344 @@
+"""Launch plans of the two models of the path, expressed as sequences of libvfx_hip calls.
+
+``VocoderEngine``  = vocoder/model/generator.py:127-145 (+ modules.py:501-528, 592-609)
+``RestorerEngine`` = restorer/model.py:103-120 (denoiser :69-99, BN_GRU :22-62) +
+                     restorer/model_kqq_bn.py:130-181 (ResUNet) + restorer/modules.py
+``Pipeline``       = voicefixer/base.py:78-85,123-135 for a batch of equal-length segments.
+
+Host work done ONCE at construction (CPU torch, "plumbing"): weight-norm folding, eval
+BatchNorm folding (into the neighbouring conv/linear weights where algebraically exact,
+otherwise kept as a fused pre-activation), packing to the [slab][CinPad][Cout] layout, H2D.
+At run time every FLOP is executed by a libvfx_hip kernel; torch only owns the buffers.
+
+Data layouts in HBM (all float32):
+  * 1-D activations: (B, C, Lp) channel-major, Lp = L rounded up to 4;
+  * UNet maps: (B, C, H*P) pitch maps, P = 128 >> level (W = P-1 valid columns);
+  * mel / logmel / denoised: (B, T, 128) frame-major (the reference's (B,1,T,128));
+  * GRU x-projections: (B, T, 1536) frame-major.
+"""
+import math
+
+import torch
+
+from . import ops, packing, weights
+from ._lib import (PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU, POST_NONE, POST_LRELU, POST_ELU, POST_TANH,
+                   POST_SIGMOID, POST_LRELU_SNAKE, PAD_ZERO, PAD_REFLECT, VfxError)
+
+
+def _up4(n):
+    return (n + 3) // 4 * 4
+
+
+def _dev(t, device):
+    return t.contiguous().float().to(device)
+
+
+class VocoderEngine:
+    """TFGAN-style 44.1 kHz generator: cond (B,128,T') -> wav (B,1,441*T')."""
+
+    def __init__(self, state, device="cuda"):
+        sd = weights.normalise_vocoder_keys(state)
+        weights.check_state(sd, weights.vocoder_manifest(), "vocoder")
+        self.device = device
+
+        def wn(prefix):
+            return weights.fold_weight_norm(sd[prefix + ".parametrizations.weight.original0"].float(),
+                                            sd[prefix + ".parametrizations.weight.original1"].float())
+
+        self.condnet = []
+        for i in (0, 2, 4, 6, 8):
+            p = "condnet.%d" % i
+            self.condnet.append((_dev(packing.pack_conv1d(wn(p)), device), _dev(sd[p + ".bias"], device)))
+        self.pre = (_dev(packing.pack_conv1d(wn("generator.1")), device), _dev(sd["generator.1.bias"], device))
+        self.stages = []
+        for j, s in enumerate(weights.UPSAMPLE_SCALES):
+            up = "generator.%d.layer" % (3 + 3 * j)
+            rs = "generator.%d" % (4 + 3 * j)
+            upw = (_dev(packing.pack_convtr1d(wn(up)), device), _dev(sd[up + ".bias"], device))
+            layers = []
+            for i in range(weights.RESSTACK_DEPTH):
+                a = "%s.layers.%d.1" % (rs, i)
+                b = "%s.layers.%d.3" % (rs, i)
+                layers.append((_dev(packing.pack_conv1d(wn(a)), device), _dev(sd[a + ".bias"], device),
+                               _dev(packing.pack_conv1d(wn(b)), device), _dev(sd[b + ".bias"], device)))
+            self.stages.append((s, upw, layers))
+        self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
+        self.act_elu = ops.Act(post=POST_ELU)
+        self.act_pre = ops.Act(post=POST_LRELU_SNAKE, post_slope=0.2)
+        self.act_c1 = ops.Act(pre=PRE_LRELU, pre_slope=0.01, post=POST_LRELU, post_slope=0.01)
+        self.act_none = ops.Act()
+        self.act_last_snake = ops.Act(post=POST_LRELU_SNAKE, post_slope=0.2)
+        self.act_last = ops.Act(post=POST_LRELU, post_slope=0.2)
+
+    def forward_cond(self, cond, Tc, stages=None):
+        """cond: device (B,128,>=Tc) channel-major.  Returns (wav buffer (B,1,Lp), L = 441*Tc)."""
+        B = cond.shape[0]
+        dev = cond.device
+        Lp = _up4(Tc)
+        a = torch.empty((B, weights.COND_CHANNELS, Lp), device=dev)
+        b = torch.empty((B, weights.COND_CHANNELS, Lp), device=dev)
+        x = cond
+        for i, (w, bias) in enumerate(self.condnet):
+            y = a if i % 2 == 0 else b
+            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu)
+            x = y
+        if stages is not None:
+            stages["condnet"] = x[:, :, :Tc]
+        # pre: ReflectionPad1d(3) + Conv1d k7 + LeakyReLU(0.2); the next UpsampleNet's x+sin(x) is fused here
+        h = torch.empty((B, weights.VOC_CHANNELS, Lp), device=dev)
+        ops.conv1d(x, self.pre[0], self.pre[1], h, Tc, 7, 1, PAD_REFLECT, self.act_pre)
+        L = Tc
+        c = weights.VOC_CHANNELS
+        nst = len(self.stages)
+        for j, (s, upw, layers) in enumerate(self.stages):
+            Lo = L * s
+            c //= 2
+            xs = torch.empty((B, c, _up4(Lo)), device=dev)
+            ys = torch.empty((B, c, _up4(Lo)), device=dev)
+            ops.convtr1d(h, upw[0], upw[1], xs, L, s, self.act_none)
+            if stages is not None:
+                stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
+            for i, (w1, b1, w2, b2) in enumerate(layers):
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1)
+                last = i == len(layers) - 1
+                act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs)  # residual updated in place
+            h = xs
+            L = Lo
+            del ys
+        wav = torch.empty((B, 1, _up4(L)), device=dev)
+        ops.conv1d_cout1(h, self.post[0], self.post[1], wav, L, 7, PAD_REFLECT, POST_TANH)
+        return wav, L
+
+    def forward(self, mel, T):
+        """mel: device (B,T,128) linear, non-normalised (Vocoder.forward semantics)."""
+        B = mel.shape[0]
+        Tc = T + T % 2 + 4
+        cond = torch.empty((B, weights.N_MELS, _up4(Tc)), device=mel.device)
+        ops.mel_to_cond(mel, cond, T)
+        return self.forward_cond(cond, Tc)
+
+
+class _ConvBlock:
+    """ConvBlockRes (restorer/modules.py:7-76) with bn2 folded into conv1."""
+
+    def __init__(self, sd, p, device):
+        s1, sh1 = weights.bn_affine(sd, p + ".bn1")
+        s2, sh2 = weights.bn_affine(sd, p + ".bn2")
+        w1 = sd[p + ".conv1.weight"].float() * s2.reshape(-1, 1, 1, 1)
+        self.cin = w1.shape[1]
+        self.cout = w1.shape[0]
+        self.w1 = _dev(packing.pack_conv2d(w1), device)
+        self.b1 = _dev(sh2, device)
+        self.w2 = _dev(packing.pack_conv2d(sd[p + ".conv2.weight"]), device)
+        self.act1 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.01, scale=_dev(s1, device), shift=_dev(sh1, device),
+                            post=POST_LRELU, post_slope=0.01)
+        self.shortcut = None
+        if (p + ".shortcut.weight") in sd:
+            self.shortcut = (_dev(packing.pack_conv2d(sd[p + ".shortcut.weight"]), device),
+                             _dev(sd[p + ".shortcut.bias"], device))
+
+    def run(self, x, y1, out, H, lp):
+        """x (B,Cin,HP) -> out (B,Cout,HP); y1 scratch (B,Cout,HP).  ``out`` may alias ``x`` when there
+        is no shortcut (the residual is read and written at the same position by the same thread)."""
+        if self.shortcut is not None:
+            ops.conv2d(x, self.shortcut[0], self.shortcut[1], out, H, lp, 1, None, cin=self.cin)
+            res = out
+        else:
+            res = x
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin)
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res)
+
+
+class RestorerEngine:
+    """mel (B,T,128) -> (logmel, denoised mel), both (B,T,128)."""
+
+    def __init__(self, state, device="cuda"):
+        sd = {k: v for k, v in state.items()}
+        weights.check_state(sd, weights.restorer_manifest(), "restorer")
+        self.device = device
+        f = lambda k: sd[k].float()
+
+        def bn_scalar(p):
+            a = f(p + ".weight") / torch.sqrt(f(p + ".running_var") + 1e-5)
+            return a.item(), (f(p + ".bias") - f(p + ".running_mean") * a).item()
+
+        def lin_in_bn(wk, bk, a, b):
+            """Linear applied to (a*x + b): W' = a W, bias' = bias + b * W.sum(1)."""
+            W, bias = f(wk), f(bk)
+            return W * a, bias + b * W.sum(dim=1)
+
+        a0, b0 = bn_scalar("denoiser.0")
+        W, bias = lin_in_bn("denoiser.1.weight", "denoiser.1.bias", a0, b0)
+        self.l1 = (_dev(packing.pack_linear(W), device), _dev(bias, device))
+        a1, b1 = bn_scalar("denoiser.3")
+        W, bias = lin_in_bn("denoiser.4.weight", "denoiser.4.bias", a1, b1)
+        self.l2 = (_dev(packing.pack_linear(W), device), _dev(bias, device))
+        self.grus = []
+        for idx in (7, 8):
+            a, b = bn_scalar("denoiser.%d.bn" % idx)
+            layers = []
+            for layer in (0, 1):
+                Ws, bs, whh, bhh = [], [], [], []
+                for suf in ("", "_reverse"):
+                    p = "denoiser.%d.gru." % idx
+                    Wih, bih = f(p + "weight_ih_l%d%s" % (layer, suf)), f(p + "bias_ih_l%d%s" % (layer, suf))
+                    if layer == 0:
+                        bih = bih + b * Wih.sum(dim=1)
+                        Wih = Wih * a
+                    Ws.append(Wih)
+                    bs.append(bih)
+                    whh.append(f(p + "weight_hh_l%d%s" % (layer, suf)).t().contiguous())
+                    bhh.append(f(p + "bias_hh_l%d%s" % (layer, suf)))
+                layers.append((_dev(packing.pack_linear(torch.cat(Ws, 0)), device), _dev(torch.cat(bs, 0), device),
+                               _dev(torch.stack(whh), device), _dev(torch.stack(bhh), device)))
+            self.grus.append(layers)
+        a4, b4 = bn_scalar("denoiser.9")
+        a5, b5 = bn_scalar("denoiser.13")
+        W, bias = f("denoiser.11.weight"), f("denoiser.11.bias")
+        self.l3 = (_dev(packing.pack_linear(W * a5), device), _dev(bias * a5 + b5, device))
+        self.act_l3 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.0, scale=torch.full((512,), a4, device=device),
+                              shift=torch.full((512,), b4, device=device), post=POST_LRELU, post_slope=0.0)
+        self.l4 = (_dev(packing.pack_linear(f("denoiser.15.weight")), device), _dev(f("denoiser.15.bias"), device))
+        self.act_relu = ops.Act(post=POST_LRELU, post_slope=0.0)
+        self.act_sigmoid = ops.Act(post=POST_SIGMOID)
+
+        self.enc = []
+        for b in range(1, 7):
+            self.enc.append([_ConvBlock(sd, "unet.encoder_block%d.conv_block%d" % (b, k), device)
+                             for k in (1, 2, 3, 4)])
+        self.center = _ConvBlock(sd, "unet.conv_block7", device)
+        self.dec = []
+        for b in range(1, 7):
+            p = "unet.decoder_block%d" % b
+            s, sh = weights.bn_affine(sd, p + ".bn1")
+            act = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.0, scale=_dev(s, device), shift=_dev(sh, device))
+            self.dec.append((_dev(packing.pack_convtr2d(sd[p + ".conv1.weight"]), device), act,
+                             [_ConvBlock(sd, "%s.conv_block%d" % (p, k), device) for k in (2, 3, 4, 5)]))
+        self.after = _ConvBlock(sd, "unet.after_conv_block1", device)
+        self.after2 = (_dev(packing.pack_cout1(sd["unet.after_conv2.weight"]), device),
+                       _dev(sd["unet.after_conv2.bias"], device))
+
+    # -- denoiser -------------------------------------------------------------------
+    def denoiser(self, mel, T):
+        """mel (B,T,128) -> mask channel-major (B,128,Tp4)."""
+        B, dev = mel.shape[0], mel.device
+        Tp4 = _up4(T)
+        x0 = torch.empty((B, 128, Tp4), device=dev)
+        ops.tm_to_cm(mel, x0, T, 128)
+        x1 = torch.empty((B, 256, Tp4), device=dev)
+        ops.conv1d(x0, self.l1[0], self.l1[1], x1, T, 1, act=self.act_relu)
+        x = torch.empty((B, 512, Tp4), device=dev)
+        ops.conv1d(x1, self.l2[0], self.l2[1], x, T, 1, act=self.act_relu)
+        gi = torch.empty((B, T, 1536), device=dev)
+        for layers in self.grus:
+            for (wih, bih, whh, bhh) in layers:
+                ops.conv1d(x, wih, bih, gi.transpose(1, 2), T, 1)
+                y = torch.empty((B, 512, Tp4), device=dev)
+                ops.gru_bidir(gi, whh, bhh, y, T)
+                x = y
+        x3 = torch.empty((B, 512, Tp4), device=dev)
+        ops.conv1d(x, self.l3[0], self.l3[1], x3, T, 1, act=self.act_l3)
+        mask = torch.empty((B, 128, Tp4), device=dev)
+        ops.conv1d(x3, self.l4[0], self.l4[1], mask, T, 1, act=self.act_sigmoid)
+        return mask
+
+    # -- ResUNet ---------------------------------------------------------------------
+    def unet(self, u, Tp):
+        """u (B,2,Tp*128) pitch map -> (B,1,Tp*128)."""
+        B, dev = u.shape[0], u.device
+        x = u
+        cats = []
+        H, lp = Tp, 7
+        for blocks in self.enc:
+            cout = blocks[0].cout
+            HP = _up4(H << lp)  # channel stride must stay a multiple of 4 floats (deepest level: H*P = 2)
+            cat = torch.empty((B, 2 * cout, HP), device=dev)
+            skip = cat[:, cout:]
+            a = torch.empty((B, cout, HP), device=dev)
+            y1 = torch.empty((B, cout, HP), device=dev)
+            blocks[0].run(x, y1, a, H, lp)
+            blocks[1].run(a, y1, a, H, lp)
+            blocks[2].run(a, y1, a, H, lp)
+            blocks[3].run(a, y1, skip, H, lp)
+            cats.append((cat, H, lp))
+            pooled = torch.empty((B, cout, _up4((H // 2) << (lp - 1))), device=dev)
+            ops.avgpool2x2(skip, pooled, H, lp)
+            x = pooled
+            H //= 2
+            lp -= 1
+        y1 = torch.empty_like(x)
+        self.center.run(x, y1, x, H, lp)
+        for (wt, act, blocks) in self.dec:
+            cat, Hs, lps = cats.pop()
+            cout = blocks[0].cout
+            assert Hs == 2 * H and lps == lp + 1
+            ops.convtr2d_3x3s2(x, wt, cat[:, :cout], H, lp, act)
+            H, lp = Hs, lps
+            HP = _up4(H << lp)
+            a = torch.empty((B, cout, HP), device=dev)
+            y1 = torch.empty((B, cout, HP), device=dev)
+            blocks[0].run(cat, y1, a, H, lp)
+            for blk in blocks[1:]:
+                blk.run(a, y1, a, H, lp)
+            x = a
+        self.after.run(x, y1, x, H, lp)
+        out = torch.empty((B, 1, H << lp), device=dev)
+        ops.conv1d_cout1(x, self.after2[0], self.after2[1], out, H << lp, 1, PAD_ZERO, POST_NONE, lp)
+        return out
+
+    def forward(self, mel, T, debug=None):
+        B, dev = mel.shape[0], mel.device
+        Tp = (T + 63) // 64 * 64
+        mask = self.denoiser(mel, T)
+        u = torch.empty((B, 2, Tp * 128), device=dev)
+        ops.unet_input(mel, mask, u, T, Tp)
+        uo = self.unet(u, Tp)
+        logmel = torch.empty((B, T, 128), device=dev)
+        den = torch.empty((B, T, 128), device=dev)
+        ops.unet_output(uo, u, mel, mask, logmel, den, T, Tp)
+        if debug is not None:
+            debug["mask"] = mask[:, :, :T]
+            debug["unet_out"] = uo.reshape(B, Tp, 128)[:, :T]
+        return logmel, den
+
+
+class Pipeline:
+    """wav batch (B,N) on the device -> restored (B,N): voicefixer/base.py:123-135 for
+    B equal-length segments at once (per-utterance peak rule)."""
+
+    def __init__(self, vocoder_state, restorer_state, device="cuda"):
+        if not torch.cuda.is_available():
+            raise VfxError("no HIP device visible: the MI355X path has no CPU fallback")
+        self.device = device
+        self.vocoder = VocoderEngine(vocoder_state, device)
+        self.restorer = RestorerEngine(restorer_state, device)
+
+    def wav_to_mel(self, wav, N):
+        B = wav.shape[0]
+        T = 1 + N // 441
+        mel = torch.empty((B, T, 128), device=wav.device)
+        ops.stft_mel(wav, mel, N)
+        return mel, T
+
+    def restore(self, wav, N, vocoder_func=None):
+        """wav: device float32 (B, >=N).  Returns device (B, N)."""
+        if N < 1025:
+            raise VfxError("segment of %d samples is too short for the reflect-padded STFT (needs > 1024); "
+                           "the reference raises inside torch reflect-pad here" % N)
+        B = wav.shape[0]
+        mel, T = self.wav_to_mel(wav, N)
+        _, den = self.restorer.forward(mel, T)
+        if vocoder_func is None:
+            y, Ly = self.vocoder.forward(den, T)
+            y = y[:, 0]
+        else:
+            y = vocoder_func(den[:, None])  # plugin hook: (B,1,T,128) -> (B,1,samples)
+            y = y.to(wav.device).float().contiguous()[:, 0]
+            Ly = y.shape[-1]
+            if Ly < N:
+                raise VfxError("your_vocoder_func returned %d samples for a %d-sample segment" % (Ly, N))
+        out = torch.empty((B, N), device=wav.device)
+        ws = torch.empty((B,), dtype=torch.int32, device=wav.device)
+        ops.post(y, Ly, out, N, ws)
+        return out
