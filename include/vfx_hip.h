@@ -73,6 +73,11 @@ int vfx_version(void);
  * proves the HIP path, not a fallback, produced a result). */
 uint64_t vfx_launch_count(void);
 
+/* Tile configuration chosen by the most recent conv-family launch of the calling thread,
+ * encoded BM*100000 + BL*100 + KC, i.e. the template instance
+ * conv_taps_kernel<BM,BL,*,*,KC> a profiler will show (bench.py's roofline bookkeeping). */
+int vfx_last_conv_tile(void);
+
 /* ---- convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------
  * Weights are pre-packed on the host as [slab][CinPad][Cout] (Cout contiguous), where a
  * slab is one kernel tap, CinPad = Cin rounded up to 8 (zero filled).  See

@@ -40,6 +40,7 @@ _I = C.c_int
 SIGNATURES = {
     "vfx_version": (_I, []),
     "vfx_launch_count": (C.c_uint64, []),
+    "vfx_last_conv_tile": (_I, []),
     "vfx_conv1d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_convtr1d_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_conv2d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _A, _P]),

@@ -323,6 +323,9 @@ static const ConvTables* device_tables(const ConvTables& tb) {
     return d;
 }
 
+static thread_local int g_last_tile = 0;
+extern "C" int vfx_last_conv_tile(void) { return g_last_tile; }
+
 static inline int floor4(int v) { return v >= 0 ? (v & ~3) : -(((-v) + 3) & ~3); }
 
 template <int BM, int BL, int WGM, int WGL, int KC>
@@ -464,6 +467,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     const size_t lds = 2ull * (a.xs_floats + a.ws_floats) * sizeof(float);
     if (lds > 160 * 1024) return VFX_ERANGE;
 
+    g_last_tile = tc.BM * 100000 + tc.BL * 100 + KC;
     dim3 grid((Lq + tc.BL - 1) / tc.BL, nphase * Cout / tc.BM, B);
 #define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                    \
     if (tc.BM == BM_ && tc.BL == BL_)                                                     \

@@ -35,6 +35,28 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+# Optional per-launch profiling of the MFMA conv family (bench.py roofline bookkeeping):
+# when PROFILE is a list, every conv-family launch is bracketed by HIP events on the launch
+# stream and (tile id, algorithmic MACs, start event, end event) is appended.
+PROFILE = None
+
+
+def _prof_begin():
+    if PROFILE is None:
+        return None
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()
+    return e
+
+
+def _prof_end(e0, macs):
+    if e0 is None:
+        return
+    e1 = torch.cuda.Event(enable_timing=True)
+    e1.record()
+    PROFILE.append((_lib.lib().vfx_last_conv_tile(), macs, e0, e1))
+
+
 class Act:
     """Bundles the fused pre/post activation of a conv launch (keeps tensors alive)."""
 
@@ -65,9 +87,11 @@ def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=Non
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
     rd = tdesc(res) if res is not None else None
+    e0 = _prof_begin()
     rc = _lib.lib().vfx_conv1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
                                    C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act), _stream())
     check(rc, "vfx_conv1d_f32")
+    _prof_end(e0, B * L * cin * cout * k)
 
 
 def convtr1d(x, w, bias, y, Lin, stride, act=None):
@@ -75,9 +99,11 @@ def convtr1d(x, w, bias, y, Lin, stride, act=None):
     B, cin = x.shape[0], x.shape[1]
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
+    e0 = _prof_begin()
     rc = _lib.lib().vfx_convtr1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(yd), B, cin, cout, Lin, stride,
                                      _act(act), _stream())
     check(rc, "vfx_convtr1d_f32")
+    _prof_end(e0, B * Lin * cin * cout * 2 * stride)
 
 
 def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None):
@@ -88,9 +114,11 @@ def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None):
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
     rd = tdesc(res) if res is not None else None
+    e0 = _prof_begin()
     rc = _lib.lib().vfx_conv2d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
                                    C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act), _stream())
     check(rc, "vfx_conv2d_f32")
+    _prof_end(e0, B * H * ((1 << pitch_log2) - 1) * cin * cout * ksize * ksize)
 
 
 def convtr2d_3x3s2(x, w, y, h, in_pitch_log2, act=None):
@@ -98,9 +126,11 @@ def convtr2d_3x3s2(x, w, y, h, in_pitch_log2, act=None):
     B, cin = x.shape[0], x.shape[1]
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
+    e0 = _prof_begin()
     rc = _lib.lib().vfx_convtr2d_3x3s2_f32(C.byref(xd), _ptr(w), C.byref(yd), B, cin, cout, h, in_pitch_log2,
                                            _act(act), _stream())
     check(rc, "vfx_convtr2d_3x3s2_f32")
+    _prof_end(e0, B * h * ((1 << in_pitch_log2) - 1) * cin * cout * 9)
 
 
 def conv1d_cout1(x, w, bias, y, L, k, pad_mode=PAD_ZERO, post=POST_NONE, out_mask_log2=0):
