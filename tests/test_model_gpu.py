@@ -35,7 +35,8 @@ def test_vocoder_golden(pipe, name):
     before = _lib.lib().vfx_launch_count()
     wav, L = pipe.vocoder.forward(mel, T)
     torch.cuda.synchronize()
-    assert _lib.lib().vfx_launch_count() - before == 1 + 5 + 1 + 4 * 17 + 1  # every op was a HIP launch
+    n_ops = 1 + 5 + 1 + 4 * 17 + 1  # every op is at least one HIP launch (conv ops: interior + boundary grids)
+    assert n_ops <= _lib.lib().vfx_launch_count() - before <= 2 * n_ops
     got = wav[:, :, :L].cpu().numpy()
     assert got.shape == g["wav"].shape
     assert _rms(got, g["wav"]) < RMS_TOL

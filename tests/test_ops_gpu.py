@@ -97,7 +97,7 @@ def test_conv1d(case):
     before = _lib.lib().vfx_launch_count()
     ops.conv1d(xd, packing.pack_conv1d(w).to(DEV), bias.to(DEV), yd, L, k, dil, pad, act, rd)
     torch.cuda.synchronize()
-    assert _lib.lib().vfx_launch_count() == before + 1
+    assert _lib.lib().vfx_launch_count() in (before + 1, before + 2)  # interior + boundary grids
     _close(yd[:, :, :L], ref, 2e-5)
     assert torch.isnan(yd[:, :, L:]).all()  # nothing written past L
 

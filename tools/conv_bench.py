@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single conv-family launches (development tool, GPU only).
+
+    python tools/conv_bench.py res4 res1 ...      # named shapes, B from --batch
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from voicefixer_amd import ops, packing, _lib  # noqa: E402
+
+SHAPES = {
+    # name: (kind, Cin, Cout, L, k, dil)
+    "res4_d1": ("c1", 64, 64, 443646, 3, 1),
+    "res4_d27": ("c1", 64, 64, 443646, 3, 27),
+    "res4_d2187": ("c1", 64, 64, 443646, 3, 2187),
+    "res3_d1": ("c1", 128, 128, 147882, 3, 1),
+    "res2_d1": ("c1", 256, 256, 49294, 3, 1),
+    "res2_d243": ("c1", 256, 256, 49294, 3, 243),
+    "res1_d1": ("c1", 512, 512, 7042, 3, 1),
+    "res1_d729": ("c1", 512, 512, 7042, 3, 729),
+    "pre_k7": ("c1r", 512, 1024, 1006, 7, 1),
+    "cond": ("c1", 512, 512, 1006, 3, 1),
+    "up1": ("t1", 1024, 512, 1006, 7, 0),
+    "up2": ("t1", 512, 256, 7042, 7, 0),
+    "up3": ("t1", 256, 128, 49294, 3, 0),
+    "up4": ("t1", 128, 64, 147882, 3, 0),
+    "unet1": ("c2", 32, 32, 1024, 7, 0),     # H=1024, lp=7
+    "unet2": ("c2", 64, 64, 512, 6, 0),
+    "unet3": ("c2", 128, 128, 256, 5, 0),
+    "unet4": ("c2", 256, 256, 128, 4, 0),
+    "unet5": ("c2", 384, 384, 64, 3, 0),
+    "gru_proj": ("c1", 512, 1536, 1001, 1, 1),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("names", nargs="*", default=["res4_d1", "res3_d1", "res2_d1", "res1_d1"])
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--iters", type=int, default=5)
+    args = ap.parse_args()
+    dev = "cuda"
+    B = args.batch
+    for name in args.names:
+        kind, cin, cout, L, k, dil = SHAPES[name]
+        g = torch.Generator().manual_seed(1)
+        act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
+        if kind in ("c1", "c1r"):
+            Lp = (L + 3) // 4 * 4
+            x = torch.randn((B, cin, Lp), device=dev)
+            y = torch.empty((B, cout, Lp), device=dev)
+            w = packing.pack_conv1d(torch.randn((cout, cin, k), generator=g) * (cin * k) ** -0.5).to(dev)
+            bias = torch.zeros(cout, device=dev)
+            pad = 1 if kind == "c1r" else 0
+            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act)
+            macs = B * L * cin * cout * k
+        elif kind == "t1":
+            s = k
+            Lp = (L + 3) // 4 * 4
+            x = torch.randn((B, cin, Lp), device=dev)
+            y = torch.empty((B, cout, (L * s + 3) // 4 * 4), device=dev)
+            w = packing.pack_convtr1d(torch.randn((cin, cout, 2 * s), generator=g) * (2 * cin) ** -0.5).to(dev)
+            bias = torch.zeros(cout, device=dev)
+            fn = lambda: ops.convtr1d(x, w, bias, y, L, s)
+            macs = B * L * cin * cout * 2 * s
+        else:
+            H, lp = L, k
+            P = 1 << lp
+            x = torch.randn((B, cin, H * P), device=dev)
+            y = torch.empty((B, cout, H * P), device=dev)
+            w = packing.pack_conv2d(torch.randn((cout, cin, 3, 3), generator=g) * (cin * 9) ** -0.5).to(dev)
+            sc = torch.ones(cin, device=dev)
+            sh = torch.zeros(cin, device=dev)
+            a2 = ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=sc, shift=sh)
+            fn = lambda: ops.conv2d(x, w, None, y, H, lp, 3, a2)
+            macs = B * H * (P - 1) * cin * cout * 9
+        fn()
+        torch.cuda.synchronize()
+        tile = _lib.lib().vfx_last_conv_tile()
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        print("%-12s B=%d tile=%d  %8.3f ms  %7.2f TFLOP/s" % (name, B, tile, ms, 2 * macs / ms / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    main()

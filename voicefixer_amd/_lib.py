@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvfx_hip.so")
+LIB_PATH = os.environ.get("VFX_LIB", os.path.join(_HERE, "libvfx_hip.so"))  # VFX_LIB: development override
 CSRC = os.path.join(_HERE, "csrc")
 
 

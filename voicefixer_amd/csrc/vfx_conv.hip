@@ -24,7 +24,11 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <type_traits>
 
+#ifndef VFX_ABL
+#define VFX_ABL 0  // development ablations: 1 = no staging in the K loop, 2 = no barrier, 4 = no MFMA
+#endif
 #define VFX_MAXPH 8
 #define VFX_MAXT 9
 
@@ -60,89 +64,48 @@ struct ConvArgs {
     int pad_mode, pre_act, post_act;
     float pre_slope, post_slope;
     int in_mask, out_mask;  // pitch-1 (e.g. 127) or 0: positions with (l & mask) == mask are structural zeros
+    int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
 };
 
+// Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
+// more than MAXXV float4 per thread; slots beyond the tile are clamped duplicates of its last
+// vector, which keeps stage_load() straight-line code (no branch => no serialising waits).
 template <int KC>
 struct StageCfg {
-    static constexpr int MAXXV = 7;  // float4 per thread for the activation tile
-    static constexpr int MAXWV = 5;  // float4 per thread for the weight tile
+    static constexpr int MAXXV = 4;              // float4 per thread for the activation tile
+    static constexpr int MAXWV = KC == 8 ? 4 : 5;  // float4 per thread for the weight tile
 };
 
-template <int BM, int BL, int WGM, int WGL, int KC>
-__global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
-    constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
-    constexpr int MAXXV = StageCfg<KC>::MAXXV, MAXWV = StageCfg<KC>::MAXWV;
-    static_assert(WGM * WGL == 4 && RM >= 1 && RL >= 1, "4 waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lo = lane & 31, hi = lane >> 5;
-    const int wm = wave / WGL, wl = wave % WGL;
-    const int q0 = blockIdx.x * BL;
-    const int m0g = blockIdx.y * BM;
-    const int ph = m0g / a.Cout;
-    const int m0 = m0g - ph * a.Cout;
-    const int b = blockIdx.z;
-    const PhaseTab* __restrict__ pt = &a.tab->ph[ph];
-    // block-uniform table entries: readfirstlane makes the uniformity provable (SGPRs, scalar branches)
-    const int nt = __builtin_amdgcn_readfirstlane(pt->ntaps);
-    const int nseg = __builtin_amdgcn_readfirstlane(pt->nseg);
-    int tap_lds[VFX_MAXT];
-#pragma unroll
-    for (int t = 0; t < VFX_MAXT; ++t) tap_lds[t] = __builtin_amdgcn_readfirstlane(pt->tap_lds[t]);
-    const int segw = a.segw;
-    const int sv = segw >> 2;                 // float4 per LDS row
-    const int xtotal = nseg * KC * sv;        // float4 in the activation tile
-    const int wtotal = nt * KC * (BM / 4);    // float4 in the weight tile
-    const int bufstride = a.xs_floats + a.ws_floats;
-
-    const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
-    const int xcs = (int)a.x_cs;
-
-    // ---- per-thread staging slots (fixed for the whole K loop) ----------------------
+// Per-thread staging state: which float4 of the activation / weight tile this thread moves.
+template <int MAXXV, int MAXWV>
+struct StageState {
     int x_l[MAXXV];    // global l of element 0 of the vector (multiple of 4, may be < 0)
-    int x_kc[MAXXV];   // row (channel within chunk), -1 = slot unused
-#pragma unroll
-    for (int j = 0; j < MAXXV; ++j) {
-        const int i = tid + 256 * j;
-        x_kc[j] = -1;
-        x_l[j] = 0;
-        if (i < xtotal) {
-            const int s = i / (KC * sv);
-            const int rem = i - s * (KC * sv);
-            const int kc = rem / sv;
-            const int v = rem - kc * sv;
-            x_kc[j] = kc;
-            x_l[j] = q0 + pt->seg_org[s] + 4 * v;
-        }
-    }
-    int w_off[MAXWV];  // element offset into w for chunk 0, -1 = unused
-#pragma unroll
-    for (int j = 0; j < MAXWV; ++j) {
-        const int i = tid + 256 * j;
-        w_off[j] = -1;
-        if (i < wtotal) {
-            const int t = i / (KC * (BM / 4));
-            const int rem = i - t * (KC * (BM / 4));
-            const int kc = rem / (BM / 4);
-            const int v = rem - kc * (BM / 4);
-            w_off[j] = (pt->tap_w[t] * a.CinPad + kc) * a.Cout + m0 + 4 * v;
-        }
-    }
-
+    int x_kc[MAXXV];   // row (channel within chunk)
+    int x_off[MAXXV];  // kc*xcs + l
+    int w_off[MAXWV];  // element offset into w for chunk 0
     float4 xv[MAXXV];
     float4 wv[MAXWV];
-    const int Lin = a.Lin;
-    const bool reflect = a.pad_mode == VFX_PAD_REFLECT;
+};
 
-    auto stage_load = [&](int c0) {
+// FAST tiles: every staged vector of every chunk lies inside the row -> unconditional float4
+// loads, no per-element range logic, no branches.  Boundary tiles run the general instance.
+template <bool FAST, int MAXXV, int MAXWV>
+__device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const ConvArgs& a,
+                                           const float* __restrict__ xb, int xcs, int c0) {
+    const float* __restrict__ xc = xb + (long long)c0 * xcs;
+    const float* __restrict__ wc = a.w + (long long)c0 * a.Cout;
 #pragma unroll
-        for (int j = 0; j < MAXXV; ++j) {
+    for (int j = 0; j < MAXXV; ++j) {
+        if constexpr (FAST) {
+            st.xv[j] = *reinterpret_cast<const float4*>(xc + st.x_off[j]);
+        } else {
+            const int Lin = a.Lin;
+            const bool reflect = a.pad_mode == VFX_PAD_REFLECT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int kc = x_kc[j];
-            if (kc >= 0 && c0 + kc < a.Cin) {
-                const float* row = xb + (long long)(c0 + kc) * xcs;
-                const int l = x_l[j];
+            const int kc = st.x_kc[j];
+            if (c0 + kc < a.Cin) {
+                const float* row = xc + (long long)kc * xcs;
+                const int l = st.x_l[j];
                 if (l >= 0 && l + 3 < Lin) {
                     v = *reinterpret_cast<const float4*>(row + l);
                 } else {
@@ -159,50 +122,125 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
                     v = make_float4(e[0], e[1], e[2], e[3]);
                 }
             }
-            xv[j] = v;
+            st.xv[j] = v;
         }
+    }
 #pragma unroll
-        for (int j = 0; j < MAXWV; ++j) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (w_off[j] >= 0) v = *reinterpret_cast<const float4*>(a.w + w_off[j] + (long long)c0 * a.Cout);
-            wv[j] = v;
-        }
-    };
+    for (int j = 0; j < MAXWV; ++j) st.wv[j] = *reinterpret_cast<const float4*>(wc + st.w_off[j]);
+}
 
-    auto stage_write = [&](int c0, float* xs, float* ws) {
+template <bool FAST, int MAXXV, int MAXWV>
+__device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, int c0, float* xs,
+                                            float* ws, const float* aff, int nxv, int nwv, int xtotal,
+                                            int wtotal, int tid) {
+    const int pre_act = a.pre_act;
+    const float pre_slope = a.pre_slope;
+    const int in_mask = a.in_mask;
 #pragma unroll
-        for (int j = 0; j < MAXXV; ++j) {
-            const int kc = x_kc[j];
-            if (kc < 0) continue;
-            float e[4] = {xv[j].x, xv[j].y, xv[j].z, xv[j].w};
-            const int l = x_l[j];
-            if (a.pre_act != VFX_PRE_NONE) {
-                float sc = 1.f, sh = 0.f;
-                const int c = c0 + kc;
-                if (a.pre_act == VFX_PRE_AFFINE_LRELU && c < a.Cin) {
-                    sc = a.pre_scale[c];
-                    sh = a.pre_shift[c];
-                }
+    for (int j = 0; j < MAXXV; ++j) {
+        if (j < nxv) {
+            float e[4] = {st.xv[j].x, st.xv[j].y, st.xv[j].z, st.xv[j].w};
+            if (pre_act == VFX_PRE_LRELU) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) e[k] = vfx_lrelu(e[k] * sc + sh, a.pre_slope);
-                // zero padding applies to the ACTIVATED input
-                if (!reflect && (l < 0 || l + 3 >= Lin || c >= a.Cin)) {
+                for (int k = 0; k < 4; ++k) e[k] = vfx_lrelu(e[k], pre_slope);
+            } else if (pre_act == VFX_PRE_AFFINE_LRELU) {
+                const int c = c0 + st.x_kc[j];
+                const float sc = aff[2 * c], sh = aff[2 * c + 1];  // LDS copy of (scale, shift)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (l + k < 0 || l + k >= Lin || c >= a.Cin) e[k] = 0.f;
+                for (int k = 0; k < 4; ++k) e[k] = vfx_lrelu(fmaf(e[k], sc, sh), pre_slope);
+                if constexpr (!FAST) {
+                    // zero padding applies to the ACTIVATED input
+                    const int l = st.x_l[j];
+                    const bool cbad = c >= a.Cin;
+                    if (a.pad_mode != VFX_PAD_REFLECT) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (l + k < 0 || l + k >= a.Lin || cbad) e[k] = 0.f;
+                    }
                 }
             }
-            if (a.in_mask) {
+            if (in_mask) {
+                const int l = st.x_l[j];
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (((l + k) & a.in_mask) == a.in_mask) e[k] = 0.f;
+                    if (((l + k) & in_mask) == in_mask) e[k] = 0.f;
             }
-            *reinterpret_cast<float4*>(xs + 4 * (tid + 256 * j)) = make_float4(e[0], e[1], e[2], e[3]);
+            int i = tid + 256 * j;
+            i = i < xtotal ? i : xtotal - 1;  // duplicates rewrite the tile's last vector with the same value
+            *reinterpret_cast<float4*>(xs + 4 * i) = make_float4(e[0], e[1], e[2], e[3]);
         }
+    }
 #pragma unroll
-        for (int j = 0; j < MAXWV; ++j)
-            if (w_off[j] >= 0) *reinterpret_cast<float4*>(ws + 4 * (tid + 256 * j)) = wv[j];
-    };
+    for (int j = 0; j < MAXWV; ++j)
+        if (j < nwv) {
+            int i = tid + 256 * j;
+            i = i < wtotal ? i : wtotal - 1;
+            *reinterpret_cast<float4*>(ws + 4 * i) = st.wv[j];
+        }
+}
+
+template <int BM, int BL, int WGM, int WGL, int KC, bool FAST>
+__global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
+    constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
+    constexpr int MAXXV = StageCfg<KC>::MAXXV, MAXWV = StageCfg<KC>::MAXWV;
+    static_assert(WGM * WGL == 4 && RM >= 1 && RL >= 1, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wm = wave / WGL, wl = wave % WGL;
+    // FAST grid covers the interior tiles [tile_lo, tile_hi); the general grid covers the rest
+    int tile = blockIdx.x;
+    if constexpr (FAST) tile += a.tile_lo;
+    else if (tile >= a.tile_lo) tile += a.tile_hi - a.tile_lo;
+    const int q0 = tile * BL;
+    const int m0g = blockIdx.y * BM;
+    const int ph = m0g / a.Cout;
+    const int m0 = m0g - ph * a.Cout;
+    const int b = blockIdx.z;
+    const PhaseTab* __restrict__ pt = &a.tab->ph[ph];
+    // block-uniform table entries: readfirstlane makes the uniformity provable (SGPRs, scalar branches)
+    const int nt = __builtin_amdgcn_readfirstlane(pt->ntaps);
+    const int nseg = __builtin_amdgcn_readfirstlane(pt->nseg);
+    int tap_lds[VFX_MAXT];
+#pragma unroll
+    for (int t = 0; t < VFX_MAXT; ++t) tap_lds[t] = __builtin_amdgcn_readfirstlane(pt->tap_lds[t]);
+    const int segw = a.segw;
+    const int sv = segw >> 2;                 // float4 per LDS row
+    const int xtotal = nseg * KC * sv;        // float4 in the activation tile
+    const int wtotal = nt * KC * (BM / 4);    // float4 in the weight tile
+    const int nxv = (xtotal + 255) >> 8;      // staging slots in use (uniform)
+    const int nwv = (wtotal + 255) >> 8;
+
+    const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
+    const int xcs = (int)a.x_cs;
+
+    // ---- per-thread staging slots (fixed for the whole K loop).  Slot indices past the end of
+    // the tile are clamped to its last vector: duplicates load and store the same value, which
+    // keeps the hot loop free of per-lane predicates.
+    StageState<MAXXV, MAXWV> st;
+#pragma unroll
+    for (int j = 0; j < MAXXV; ++j) {
+        int i = tid + 256 * j;
+        i = i < xtotal ? i : xtotal - 1;
+        const int s = i / (KC * sv);
+        const int rem = i - s * (KC * sv);
+        const int kc = rem / sv;
+        const int v = rem - kc * sv;
+        st.x_kc[j] = kc;
+        st.x_l[j] = q0 + pt->seg_org[s] + 4 * v;
+        st.x_off[j] = kc * xcs + st.x_l[j];
+    }
+#pragma unroll
+    for (int j = 0; j < MAXWV; ++j) {
+        int i = tid + 256 * j;
+        i = i < wtotal ? i : wtotal - 1;
+        const int t = i / (KC * (BM / 4));
+        const int rem = i - t * (KC * (BM / 4));
+        const int kc = rem / (BM / 4);
+        const int v = rem - kc * (BM / 4);
+        st.w_off[j] = (pt->tap_w[t] * a.CinPad + kc) * a.Cout + m0 + 4 * v;
+    }
 
     f32x16 acc[RM][RL];
 #pragma unroll
@@ -212,22 +250,32 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (a.Cin + KC - 1) / KC;
     const int a_col = wm * WMT + lo;  // column into the weight tile row
     const int b_col = wl * WLT + lo;  // column into the activation tile row
+    const int nchunks = (a.Cin + KC - 1) / KC;
+    const int bufstride = a.xs_floats + a.ws_floats;
 
-    stage_load(0);
-    stage_write(0, smem, smem + a.xs_floats);
+    // per-channel (scale, shift) of the fused BatchNorm pre-activation: one LDS copy per workgroup
+    float* aff = smem + 2 * bufstride;
+    if (a.pre_act == VFX_PRE_AFFINE_LRELU) {
+        for (int c = tid; c < a.CinPad; c += 256) {
+            aff[2 * c] = c < a.Cin ? a.pre_scale[c] : 1.f;
+            aff[2 * c + 1] = c < a.Cin ? a.pre_shift[c] : 0.f;
+        }
+        __syncthreads();
+    }
+    stage_load<FAST>(st, a, xb, xcs, 0);
+    stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid);
     __syncthreads();
-
     for (int ch = 0; ch < nchunks; ++ch) {
         const float* xs = smem + (ch & 1) * bufstride;
         const float* ws = xs + a.xs_floats;
-        if (ch + 1 < nchunks) stage_load((ch + 1) * KC);
-
+#if !(VFX_ABL & 1)
+        if (ch + 1 < nchunks) stage_load<FAST>(st, a, xb, xcs, (ch + 1) * KC);
+#endif
 #pragma unroll
         for (int t = 0; t < VFX_MAXT; ++t) {
-            if (t < nt) {
+            if ((t < nt) && !(VFX_ABL & 4)) {
                 const float* xt = xs + tap_lds[t] + b_col;
                 const float* wt = ws + t * (KC * BM) + a_col;
 #pragma unroll
@@ -245,12 +293,15 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
                 }
             }
         }
-
+#if !(VFX_ABL & 1)
         if (ch + 1 < nchunks) {
             float* nxs = smem + ((ch + 1) & 1) * bufstride;
-            stage_write((ch + 1) * KC, nxs, nxs + a.xs_floats);
+            stage_write<FAST>(st, a, (ch + 1) * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid);
         }
+#endif
+#if !(VFX_ABL & 2)
         __syncthreads();
+#endif
     }
 
     // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -328,10 +379,10 @@ extern "C" int vfx_last_conv_tile(void) { return g_last_tile; }
 
 static inline int floor4(int v) { return v >= 0 ? (v & ~3) : -(((-v) + 3) & ~3); }
 
-template <int BM, int BL, int WGM, int WGL, int KC>
-static int launch_cfg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+template <int BM, int BL, int WGM, int WGL, int KC, bool FAST>
+static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC>;
+    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC, FAST>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -341,6 +392,17 @@ static int launch_cfg(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     VFX_LAUNCHED();
     return vfx_last_error();
+}
+
+// interior tiles go to the FAST instance, the (few) boundary tiles to the general one
+template <int BM, int BL, int WGM, int WGL, int KC>
+static int launch_cfg(const ConvArgs& a, int ntiles, int gy, int gz, size_t lds, hipStream_t s) {
+    const int nfast = a.tile_hi - a.tile_lo;
+    int rc = VFX_OK;
+    if (nfast > 0) rc = launch_one<BM, BL, WGM, WGL, KC, true>(a, dim3(nfast, gy, gz), lds, s);
+    if (rc == VFX_OK && ntiles - nfast > 0)
+        rc = launch_one<BM, BL, WGM, WGL, KC, false>(a, dim3(ntiles - nfast, gy, gz), lds, s);
+    return rc;
 }
 
 static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpec* phs, int BL, int KC) {
@@ -434,15 +496,12 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     int maxnt = 0;
     for (int p = 0; p < nphase; ++p) maxnt = phs[p].ntaps > maxnt ? phs[p].ntaps : maxnt;
     if (maxnt < 1 || maxnt > VFX_MAXT) return VFX_EINVAL;
-    const int KC = maxnt <= 4 ? 8 : 4;
-
     // tile choice: maximise (tile efficiency) x (tail efficiency along L) x (wave quantisation)
     int best = -1;
     float best_score = -1.f;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileCfg& t = kTiles[i];
         if (Cout % t.BM) continue;
-        if ((long long)maxnt * KC * t.BM > 5 * 1024) continue;
         const long long lt = (Lq + t.BL - 1) / t.BL;
         const long long nwg = lt * (long long)(nphase * Cout / t.BM) * B;
         const float tail = (float)Lq / (float)(lt * t.BL);
@@ -454,25 +513,51 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     if (best < 0) return VFX_EINVAL;
     const TileCfg& tc = kTiles[best];
 
+    // K-chunk depth: 8 channels per chunk unless the staged tiles would need more than 4 float4 per
+    // thread (activations) / the weight tile more than its slot budget -> 4 channels per chunk
     ConvTables tb;
-    std::memset(&tb, 0, sizeof(tb));
-    int rc = fill_segments(a, tb, nphase, phs, tc.BL, KC);
-    if (rc) return rc;
-    int maxseg = 0;
-    for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
+    int KC = 8;
+    for (;;) {
+        std::memset(&tb, 0, sizeof(tb));
+        int rc = fill_segments(a, tb, nphase, phs, tc.BL, KC);
+        if (rc) return rc;
+        int maxseg = 0;
+        for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
+        const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * 256;
+        const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 8 ? 4 : 5) * 1024;
+        if (xfit && wfit) break;
+        if (KC == 4) return VFX_ERANGE;
+        KC = 4;
+    }
     a.tab = device_tables(tb);
     if (!a.tab) return VFX_EINVAL;
-    if ((long long)maxseg * KC * (a.segw / 4) > 7 * 256) return VFX_ERANGE;
     a.ws_floats = maxnt * KC * tc.BM;
-    const size_t lds = 2ull * (a.xs_floats + a.ws_floats) * sizeof(float);
+    const size_t lds = (2ull * (a.xs_floats + a.ws_floats) + 2ull * a.CinPad) * sizeof(float);
     if (lds > 160 * 1024) return VFX_ERANGE;
 
     g_last_tile = tc.BM * 100000 + tc.BL * 100 + KC;
-    dim3 grid((Lq + tc.BL - 1) / tc.BL, nphase * Cout / tc.BM, B);
+    // interior tiles: all staged vectors of all phases inside [0, Lin) and no channel tail
+    const int ntiles = (Lq + tc.BL - 1) / tc.BL;
+    {
+        int seg_lo = 0x7fffffff, seg_hi = -0x7fffffff;
+        for (int p = 0; p < nphase; ++p)
+            for (int sg = 0; sg < tb.ph[p].nseg; ++sg) {
+                seg_lo = tb.ph[p].seg_org[sg] < seg_lo ? tb.ph[p].seg_org[sg] : seg_lo;
+                seg_hi = tb.ph[p].seg_org[sg] > seg_hi ? tb.ph[p].seg_org[sg] : seg_hi;
+            }
+        int tlo = seg_lo < 0 ? (-seg_lo + tc.BL - 1) / tc.BL : 0;
+        const long long room = (long long)Lin - seg_hi - a.segw;
+        int thi = room >= 0 ? (int)(room / tc.BL) + 1 : 0;
+        if (thi > ntiles) thi = ntiles;
+        if (tlo > thi || Cin % KC != 0) { tlo = 0; thi = 0; }
+        a.tile_lo = tlo;
+        a.tile_hi = thi;
+    }
+    const int gy = nphase * Cout / tc.BM;
 #define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                    \
     if (tc.BM == BM_ && tc.BL == BL_)                                                     \
-        return KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, grid, lds, stream)        \
-                       : launch_cfg<BM_, BL_, WGM_, WGL_, 4>(a, grid, lds, stream);
+        return KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, ntiles, gy, B, lds, stream) \
+                       : launch_cfg<BM_, BL_, WGM_, WGL_, 4>(a, ntiles, gy, B, lds, stream);
     VFX_CASE(128, 128, 2, 2)
     VFX_CASE(64, 256, 1, 4)
     VFX_CASE(128, 64, 4, 1)
