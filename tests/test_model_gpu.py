@@ -95,7 +95,8 @@ def test_batch_equals_single(pipe):
     batch = pipe.restore(wavs.cuda(), n).cpu()
     for b in range(3):
         single = pipe.restore(wavs[b:b + 1].cuda(), n).cpu()
-        assert torch.equal(single[0], batch[b])  # bit-identical: same kernels, same tiles
+        # same algorithm, but the tile / K-chunk heuristics may differ with B (fp32 summation order)
+        assert (single[0] - batch[b]).abs().max() < 2e-5
 
 
 def test_linearity_free_properties(pipe):
