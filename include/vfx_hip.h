@@ -159,12 +159,15 @@ int vfx_unet_output_f32(const float* unet_out, const float* unet_in, const float
                         const vfx_tensor* mask, float* logmel, float* denoised, int B, int T,
                         int Tp, vfx_stream_t stream);
 
-/* 2-layer-stack building block: one bidirectional GRU layer, hidden 256, PyTorch gate order
- * (r,z,n), h0 = 0.  gi = x-projections incl. b_ih, frame-major (B,T,1536) = [fwd r,z,n |
- * bwd r,z,n].  whh_t = [2][256][768] (transposed W_hh per direction), bhh = [2][768].
- * out is channel-major (B,512,*): fwd in channels 0..255, bwd in 256..511.
+/* One bidirectional GRU layer, hidden 256, PyTorch gate order (r,z,n), h0 = 0: the recurrent
+ * part.  gi = x-projections incl. b_ih, frame-major (B,T,1536) = [fwd r,z,n | bwd r,z,n].
+ * whh_packed = W_hh of both directions in the layout of voicefixer_amd/packing.py::pack_gru_whh
+ * (per direction: register-resident rows, LDS-resident rows, L2-streamed rows; the split is
+ * reported by vfx_gru_layout).  bhh = [2][768].  out is channel-major (B,512,*): fwd in channels
+ * 0..255, bwd in 256..511.
  * Replaces the recurrent part of torch.nn.GRU in voicefixer/restorer/model.py:37-44,57-62. */
-int vfx_gru_bidir_f32(const float* gi, const float* whh_t, const float* bhh,
+void vfx_gru_layout(int* kreg, int* klds, int* kstr);
+int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const float* bhh,
                       const vfx_tensor* out, int B, int T, vfx_stream_t stream);
 
 /* ---- synthesis front/back -------------------------------------------------------- */

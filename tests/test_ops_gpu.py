@@ -292,7 +292,7 @@ def test_gru_bidir():
         gis.append(x @ params["w_ih" + suf].t() + params["b_ih" + suf])
     ref = torch.cat(outs, -1)  # (B,T,512)
     gi = torch.cat(gis, -1).contiguous().to(DEV)  # (B,T,1536)
-    whh_t = torch.stack([params["w_hh"].t().contiguous(), params["w_hh_reverse"].t().contiguous()]).to(DEV)
+    whh_t = packing.pack_gru_whh(params["w_hh"], params["w_hh_reverse"], *ops.gru_layout()).to(DEV)
     bhh = torch.stack([params["b_hh"], params["b_hh_reverse"]]).to(DEV)
     out = torch.full((B, 512, 40), float("nan"), device=DEV)
     ops.gru_bidir(gi, whh_t, bhh, out, T)

@@ -5,95 +5,200 @@
 // is strictly sequential in t:
 //     gh = W_hh h + b_hh ; r = s(gi_r+gh_r) ; z = s(gi_z+gh_z) ; n = tanh(gi_n + r*gh_n)
 //     h' = (1-z)*n + z*h
-// One workgroup owns one (utterance, direction) sequence, so there is NO inter-workgroup
-// synchronisation per step.  Thread j owns hidden unit j (rows j, 256+j, 512+j of W_hh).
-// W_hh^T (768 KB per direction) does not fit a CU: KREG k-rows live in VGPRs for the whole
-// sequence (256 threads = one wave per SIMD = the full 512-VGPR budget), the rest streams
-// from L2 every step (coalesced: thread j reads whh_t[k][g*256+j]).  h is double buffered
-// in LDS: one barrier per step.
+// One workgroup (512 threads) owns one (utterance, direction) sequence, so there is NO
+// inter-workgroup synchronisation per step.  Thread (j, half) owns hidden unit j (rows j,
+// 256+j, 512+j of W_hh) over half of the k range; the halves are combined through LDS.
+// W_hh (768 KB per direction) does not fit one CU, so it is split three ways, fixed for the
+// whole sequence:
+//     KREG k-rows per half  in VGPRs          (2 waves per SIMD => 256 registers per thread)
+//     KLDS k-rows per half  in LDS            (~150 KB)
+//     KSTR k-rows per half  streamed from L2  every step, as coalesced 16-byte buffer loads
+//                                             through two small register buffers (2 in flight)
+// The packed weight layout is produced by voicefixer_amd/packing.py::pack_gru_whh and
+// documented in include/vfx_hip.h.
 #include "vfx_common.h"
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #define GRU_H 256
 #define GRU_G 768
+#define GRU_KREG 40
+#define GRU_KLDS 24
+#define GRU_KSTR (128 - GRU_KREG - GRU_KLDS)  // 48
+#define GRU_NQ (GRU_KSTR / 4)
 
-template <int KREG>
-__global__ __launch_bounds__(256, 1) void gru_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
+// packed sizes (floats) per direction
+#define GRU_R_FLOATS (2 * GRU_KREG * GRU_G)
+#define GRU_L_FLOATS (2 * GRU_KLDS * GRU_G)
+#define GRU_S_FLOATS (2 * GRU_NQ * 3 * GRU_H * 4)
+
+__global__ __launch_bounds__(512, 1) void gru_kernel(const float* __restrict__ gi, const float* __restrict__ wpk,
                                                      const float* __restrict__ bhh, float* __restrict__ out,
                                                      long long o_bs, long long o_cs, int T) {
-    __shared__ float hbuf[2][GRU_H];
-    const int j = threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* wl = lds;                               // [2][KLDS][768]
+    float* hbuf = wl + GRU_L_FLOATS;               // [2][256]
+    float* part = hbuf + 2 * GRU_H;                // [3][256] partial sums of half 1
+    const int tid = threadIdx.x;
+    const int j = tid & 255, half = tid >> 8;
     const int b = blockIdx.x, dir = blockIdx.y;
-    const float* W = whh_t + (long long)dir * GRU_H * GRU_G;
+    const float* Wd = wpk + (long long)dir * (GRU_R_FLOATS + GRU_L_FLOATS + GRU_S_FLOATS);
+    const float* WR = Wd + (long long)half * GRU_KREG * GRU_G;
+    const float* WL = Wd + GRU_R_FLOATS;
     const float* g = gi + (long long)b * T * (2 * GRU_G) + dir * GRU_G;
     float* o = out + (long long)b * o_bs + (long long)(dir * GRU_H + j) * o_cs;
-    const float br = bhh[dir * GRU_G + j], bz = bhh[dir * GRU_G + GRU_H + j], bn = bhh[dir * GRU_G + 2 * GRU_H + j];
 
-    float wr[KREG > 0 ? KREG : 1], wz[KREG > 0 ? KREG : 1], wn[KREG > 0 ? KREG : 1];
+    float wr[GRU_KREG], wz[GRU_KREG], wn[GRU_KREG];
 #pragma unroll
-    for (int k = 0; k < KREG; ++k) {
-        wr[k] = W[k * GRU_G + j];
-        wz[k] = W[k * GRU_G + GRU_H + j];
-        wn[k] = W[k * GRU_G + 2 * GRU_H + j];
+    for (int k = 0; k < GRU_KREG; ++k) {
+        wr[k] = WR[k * GRU_G + j];
+        wz[k] = WR[k * GRU_G + GRU_H + j];
+        wn[k] = WR[k * GRU_G + 2 * GRU_H + j];
     }
-
-    hbuf[0][j] = 0.f;
+    for (int i = tid; i < GRU_L_FLOATS; i += 512) wl[i] = WL[i];
+    float br = 0.f, bz = 0.f, bn = 0.f;
+    if (half == 0) {
+        br = bhh[dir * GRU_G + j];
+        bz = bhh[dir * GRU_G + GRU_H + j];
+        bn = bhh[dir * GRU_G + 2 * GRU_H + j];
+    }
+    if (tid < 2 * GRU_H) hbuf[tid] = 0.f;
     float hj = 0.f;
     __syncthreads();
 
     int t = dir ? T - 1 : 0;
     const int dt = dir ? -1 : 1;
-    float gr = g[(long long)t * (2 * GRU_G) + j];
-    float gz = g[(long long)t * (2 * GRU_G) + GRU_H + j];
-    float gn = g[(long long)t * (2 * GRU_G) + 2 * GRU_H + j];
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (half == 0) {
+        gr = g[(long long)t * (2 * GRU_G) + j];
+        gz = g[(long long)t * (2 * GRU_G) + GRU_H + j];
+        gn = g[(long long)t * (2 * GRU_G) + 2 * GRU_H + j];
+    }
+    const float* wlh = wl + half * GRU_KLDS * GRU_G + j;
+    // uniform base (both halves), per-lane voffset = half block + j*16
+    const __amdgpu_buffer_rsrc_t srd = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(Wd + GRU_R_FLOATS + GRU_L_FLOATS), (short)0, (int)(GRU_S_FLOATS * 4), 0x00020000);
+    const int svoff = (half * GRU_NQ * 3 * GRU_H + j) * 16;
 
     for (int s = 0; s < T; ++s) {
-        const float* h = hbuf[s & 1];
+        const float* h = hbuf + (s & 1) * GRU_H + half * 128;  // this half's k range
+        // ---- streamed rows go through two small register buffers (QB quads of k each, NB batches):
+        // two batches are in flight; a buffer is refilled right after it has been consumed.
+        constexpr int QB = 2, NB = GRU_NQ / QB;
+        static_assert(GRU_NQ % (2 * QB) == 0, "streamed rows come in an even number of batches");
+        float4 s0[QB][3], s1[QB][3];
+        // buffer loads: one VGPR offset + a scalar offset per load, so the streamed loads do not each
+        // pin a 64-bit VGPR address across the step loop
+#define GRU_LOAD(buf, batch)                                                                     \
+    _Pragma("unroll") for (int q = 0; q < QB; ++q) _Pragma("unroll") for (int gg = 0; gg < 3; ++gg) { \
+        const u32x4 r_ = __builtin_amdgcn_raw_buffer_load_b128(srd, svoff, ((((batch)*QB + q) * 3 + gg) * GRU_H) * 16, 0); \
+        buf[q][gg] = make_float4(__uint_as_float(r_.x), __uint_as_float(r_.y), __uint_as_float(r_.z), __uint_as_float(r_.w)); \
+    }
+#define GRU_USE(buf, batch)                                                                      \
+    _Pragma("unroll") for (int q = 0; q < QB; ++q) {                                             \
+        const float4 hv = *reinterpret_cast<const float4*>(h + GRU_KREG + GRU_KLDS + 4 * ((batch)*QB + q)); \
+        ar2 = fmaf(buf[q][0].x, hv.x, ar2); az2 = fmaf(buf[q][1].x, hv.x, az2); an2 = fmaf(buf[q][2].x, hv.x, an2); \
+        ar2 = fmaf(buf[q][0].y, hv.y, ar2); az2 = fmaf(buf[q][1].y, hv.y, az2); an2 = fmaf(buf[q][2].y, hv.y, an2); \
+        ar2 = fmaf(buf[q][0].z, hv.z, ar2); az2 = fmaf(buf[q][1].z, hv.z, az2); an2 = fmaf(buf[q][2].z, hv.z, an2); \
+        ar2 = fmaf(buf[q][0].w, hv.w, ar2); az2 = fmaf(buf[q][1].w, hv.w, az2); an2 = fmaf(buf[q][2].w, hv.w, an2); \
+    }
+        GRU_LOAD(s0, 0)
+        GRU_LOAD(s1, 1)
+        __builtin_amdgcn_sched_barrier(0);
         // prefetch next step's x-projection
         const int tn = t + dt;
         float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-        if (s + 1 < T) {
+        if (half == 0 && s + 1 < T) {
             ngr = g[(long long)tn * (2 * GRU_G) + j];
             ngz = g[(long long)tn * (2 * GRU_G) + GRU_H + j];
             ngn = g[(long long)tn * (2 * GRU_G) + 2 * GRU_H + j];
         }
-        float ar = 0.f, az = 0.f, an = 0.f;
+        float ar = br, az = bz, an = bn;
+        // ---- register-resident rows
 #pragma unroll
-        for (int k = 0; k < KREG; k += 4) {
+        for (int k = 0; k < GRU_KREG; k += 4) {
             const float4 hv = *reinterpret_cast<const float4*>(h + k);
             ar = fmaf(wr[k], hv.x, ar); az = fmaf(wz[k], hv.x, az); an = fmaf(wn[k], hv.x, an);
             ar = fmaf(wr[k + 1], hv.y, ar); az = fmaf(wz[k + 1], hv.y, az); an = fmaf(wn[k + 1], hv.y, an);
             ar = fmaf(wr[k + 2], hv.z, ar); az = fmaf(wz[k + 2], hv.z, az); an = fmaf(wn[k + 2], hv.z, an);
             ar = fmaf(wr[k + 3], hv.w, ar); az = fmaf(wz[k + 3], hv.w, az); an = fmaf(wn[k + 3], hv.w, an);
+            if ((k & 7) == 4) __builtin_amdgcn_sched_barrier(0);  // bound how far the h reads are hoisted
         }
         float ar2 = 0.f, az2 = 0.f, an2 = 0.f;
-#pragma unroll 8
-        for (int k = KREG; k < GRU_H; k += 4) {
-            const float4 hv = *reinterpret_cast<const float4*>(h + k);
-            const float* w0 = W + (long long)k * GRU_G + j;
-            ar2 = fmaf(w0[0], hv.x, ar2); az2 = fmaf(w0[GRU_H], hv.x, az2); an2 = fmaf(w0[2 * GRU_H], hv.x, an2);
-            ar2 = fmaf(w0[GRU_G], hv.y, ar2); az2 = fmaf(w0[GRU_G + GRU_H], hv.y, az2); an2 = fmaf(w0[GRU_G + 2 * GRU_H], hv.y, an2);
-            ar2 = fmaf(w0[2 * GRU_G], hv.z, ar2); az2 = fmaf(w0[2 * GRU_G + GRU_H], hv.z, az2); an2 = fmaf(w0[2 * GRU_G + 2 * GRU_H], hv.z, an2);
-            ar2 = fmaf(w0[3 * GRU_G], hv.w, ar2); az2 = fmaf(w0[3 * GRU_G + GRU_H], hv.w, az2); an2 = fmaf(w0[3 * GRU_G + 2 * GRU_H], hv.w, an2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NB; i += 2) {
+            GRU_USE(s0, i)
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 2 < NB) { GRU_LOAD(s0, i + 2) }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) {
+                // ---- LDS-resident rows (placed here so they overlap the refill of s0)
+#pragma unroll
+                for (int k = 0; k < GRU_KLDS; k += 4) {
+                    const float4 hv = *reinterpret_cast<const float4*>(h + GRU_KREG + k);
+                    const float* w0 = wlh + k * GRU_G;
+                    ar2 = fmaf(w0[0], hv.x, ar2); az2 = fmaf(w0[GRU_H], hv.x, az2); an2 = fmaf(w0[2 * GRU_H], hv.x, an2);
+                    ar2 = fmaf(w0[GRU_G], hv.y, ar2); az2 = fmaf(w0[GRU_G + GRU_H], hv.y, az2); an2 = fmaf(w0[GRU_G + 2 * GRU_H], hv.y, an2);
+                    ar2 = fmaf(w0[2 * GRU_G], hv.z, ar2); az2 = fmaf(w0[2 * GRU_G + GRU_H], hv.z, az2); an2 = fmaf(w0[2 * GRU_G + 2 * GRU_H], hv.z, an2);
+                    ar2 = fmaf(w0[3 * GRU_G], hv.w, ar2); az2 = fmaf(w0[3 * GRU_G + GRU_H], hv.w, az2); an2 = fmaf(w0[3 * GRU_G + 2 * GRU_H], hv.w, an2);
+                    if ((k & 7) == 4) __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            GRU_USE(s1, i + 1)
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 3 < NB) { GRU_LOAD(s1, i + 3) }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        ar += ar2 + br; az += az2 + bz; an += an2 + bn;
-        const float r = 1.f / (1.f + expf(-(gr + ar)));
-        const float z = 1.f / (1.f + expf(-(gz + az)));
-        const float n = tanhf(gn + r * an);
-        hj = (1.f - z) * n + z * hj;
-        hbuf[(s + 1) & 1][j] = hj;
-        o[t] = hj;
-        gr = ngr; gz = ngz; gn = ngn;
+#undef GRU_LOAD
+#undef GRU_USE
+        ar += ar2; az += az2; an += an2;
+        if (half == 1) {
+            part[j] = ar;
+            part[GRU_H + j] = az;
+            part[2 * GRU_H + j] = an;
+        }
+        __syncthreads();
+        if (half == 0) {
+            ar += part[j];
+            az += part[GRU_H + j];
+            an += part[2 * GRU_H + j];
+            const float r = 1.f / (1.f + expf(-(gr + ar)));
+            const float z = 1.f / (1.f + expf(-(gz + az)));
+            const float n = tanhf(gn + r * an);
+            hj = (1.f - z) * n + z * hj;
+            hbuf[((s + 1) & 1) * GRU_H + j] = hj;
+            o[t] = hj;
+            gr = ngr; gz = ngz; gn = ngn;
+        }
         t = tn;
         __syncthreads();
     }
 }
 
-extern "C" int vfx_gru_bidir_f32(const float* gi, const float* whh_t, const float* bhh, const vfx_tensor* out, int B,
-                                 int T, vfx_stream_t stream) {
-    if (!gi || !whh_t || !bhh || !out || !out->ptr || B <= 0 || T <= 0 || B > 65535) return VFX_EINVAL;
+extern "C" int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const float* bhh, const vfx_tensor* out,
+                                 int B, int T, vfx_stream_t stream) {
+    if (!gi || !whh_packed || !bhh || !out || !out->ptr || B <= 0 || T <= 0 || B > 65535) return VFX_EINVAL;
     if (out->lstride != 1) return VFX_EALIGN;
-    hipLaunchKernelGGL(gru_kernel<112>, dim3(B, 2), dim3(256), 0, (hipStream_t)stream, gi, whh_t, bhh,
+    if (!vfx_aligned16(whh_packed)) return VFX_EALIGN;
+    static bool attr_set = false;
+    const size_t lds = (GRU_L_FLOATS + 2 * GRU_H + 3 * GRU_H) * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gru_kernel, dim3(B, 2), dim3(512), lds, (hipStream_t)stream, gi, whh_packed, bhh,
                        (float*)out->ptr, out->bstride, out->cstride, T);
     VFX_LAUNCHED();
     return vfx_last_error();
+}
+
+// layout constants for the host-side packer (keeps Python and the kernel in sync)
+extern "C" void vfx_gru_layout(int* kreg, int* klds, int* kstr) {
+    *kreg = GRU_KREG;
+    *klds = GRU_KLDS;
+    *kstr = GRU_KSTR;
 }

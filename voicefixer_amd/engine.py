@@ -188,10 +188,11 @@ class RestorerEngine:
                         Wih = Wih * a
                     Ws.append(Wih)
                     bs.append(bih)
-                    whh.append(f(p + "weight_hh_l%d%s" % (layer, suf)).t().contiguous())
+                    whh.append(f(p + "weight_hh_l%d%s" % (layer, suf)))
                     bhh.append(f(p + "bias_hh_l%d%s" % (layer, suf)))
                 layers.append((_dev(packing.pack_linear(torch.cat(Ws, 0)), device), _dev(torch.cat(bs, 0), device),
-                               _dev(torch.stack(whh), device), _dev(torch.stack(bhh), device)))
+                               _dev(packing.pack_gru_whh(whh[0], whh[1], *ops.gru_layout()), device),
+                               _dev(torch.stack(bhh), device)))
             self.grus.append(layers)
         a4, b4 = bn_scalar("denoiser.9")
         a5, b5 = bn_scalar("denoiser.13")

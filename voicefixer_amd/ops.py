@@ -199,7 +199,14 @@ def unet_output(unet_out, unet_in, mel, mask, logmel, denoised, T, Tp):
                                          _ptr(denoised), mel.shape[0], T, Tp, _stream()), "vfx_unet_output_f32")
 
 
+def gru_layout():
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    _lib.lib().vfx_gru_layout(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value
+
+
 def gru_bidir(gi, whh_t, bhh, out, T):
+    """whh_t: packed by packing.pack_gru_whh(..., *gru_layout())."""
     _need_cuda(gi, whh_t, bhh, out)
     od = tdesc(out)
     check(_lib.lib().vfx_gru_bidir_f32(_ptr(gi), _ptr(whh_t), _ptr(bhh), C.byref(od), gi.shape[0], T, _stream()),

@@ -45,3 +45,24 @@ def pack_linear(w):
 def pack_cout1(w):
     """Conv weight (1, Cin, k[, 1]) -> [Cin][k]."""
     return w.reshape(w.shape[1], -1).contiguous().float()
+
+
+def pack_gru_whh(w_hh_fwd, w_hh_bwd, kreg, klds, kstr):
+    """W_hh (768, 256) per direction -> the packed recurrent-weight buffer of vfx_gru_bidir_f32.
+
+    Per direction, with k = half*128 + ... the reduction index and n = gate*256 + unit the row:
+      R: [2 halves][kreg][768]            k = half*128 + kk            (lives in VGPRs)
+      L: [2 halves][klds][768]            k = half*128 + kreg + kk     (lives in LDS)
+      S: [2 halves][kstr/4][3][256][4]    k = half*128 + kreg + klds + 4*q + e  (streamed, float4)
+    """
+    assert kreg + klds + kstr == 128 and kstr % 4 == 0
+    out = []
+    for w in (w_hh_fwd, w_hh_bwd):
+        wt = w.float().t().contiguous()  # (256 k, 768 n)
+        wt = wt.reshape(2, 128, 768)
+        r = wt[:, :kreg].reshape(-1)
+        l = wt[:, kreg:kreg + klds].reshape(-1)
+        st = wt[:, kreg + klds:].reshape(2, kstr // 4, 4, 3, 256)  # half, q, e, gate, unit
+        st = st.permute(0, 1, 3, 4, 2).reshape(-1)                   # half, q, gate, unit, e
+        out.append(torch.cat([r, l, st]))
+    return torch.cat(out).contiguous()
