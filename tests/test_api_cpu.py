@@ -1,0 +1,124 @@
+"""Host-side behaviour of the drop-in API that needs no GPU: error contract, the C ABI
+library exporting every declared symbol, packing layouts, I/O quantisation."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import voicefixer_amd
+from voicefixer_amd import _lib, api, audio_io, packing, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_exported():
+    """Every function declared in include/vfx_hip.h is exported by libvfx_hip.so and bound."""
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    hdr = open(os.path.join(ROOT, "include", "vfx_hip.h")).read()
+    names = set(re.findall(r"\b(vfx_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"vfx_tensor", "vfx_act"}
+    assert len(names) >= 18
+    h = _lib.lib()
+    for n in sorted(names):
+        assert hasattr(h, n), n
+        assert n in _lib.SIGNATURES, "%s not bound in _lib.SIGNATURES" % n
+    assert h.vfx_version() >= 100
+
+
+def test_missing_checkpoints_raise_like_reference(tmp_path, monkeypatch):
+    monkeypatch.setenv("HOME", str(tmp_path))
+    with pytest.raises(RuntimeError, match="Error 0"):
+        voicefixer_amd.VoiceFixer()
+    with pytest.raises(RuntimeError, match="Error 1"):
+        voicefixer_amd.Vocoder(44100)
+    with pytest.raises(RuntimeError, match="44100"):
+        voicefixer_amd.Vocoder(16000)
+
+
+def test_no_cpu_fallback(seeded_states):
+    """Without a HIP device the product path raises instead of computing on the CPU."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    vf = voicefixer_amd.VoiceFixer.from_state(*seeded_states)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        vf.restore_inmem(np.zeros(4410, np.float32), cuda=False)
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        voicefixer_amd.Vocoder.from_state(seeded_states[0]).forward(torch.ones(1, 1, 8, 128))
+
+
+def test_modes(seeded_states):
+    vf = voicefixer_amd.VoiceFixer.from_state(*seeded_states)
+    for mode in (1, 2):
+        with pytest.raises(NotImplementedError):
+            vf.restore_inmem(np.zeros(4410, np.float32), mode=mode)
+    with pytest.raises(ValueError):
+        vf.restore_inmem(np.zeros(4410, np.float32), mode=7)
+
+
+def test_product_path_does_not_import_oracle():
+    """voicefixer_amd must never reach into oracle/ (test infrastructure)."""
+    pkg = os.path.join(ROOT, "voicefixer_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+            assert "ref_shim" not in src, fn
+
+
+def test_packing_layouts():
+    w = torch.arange(2 * 3 * 5, dtype=torch.float32).reshape(2, 3, 5)  # (Cout=2, Cin=3, k=5)
+    p = packing.pack_conv1d(w)
+    assert p.shape == (5, 8, 2) and torch.equal(p[4, 2], w[:, 2, 4]) and (p[:, 3:] == 0).all()
+    wt = torch.randn(3, 2, 6)  # ConvTranspose1d (Cin, Cout, k)
+    p = packing.pack_convtr1d(wt)
+    assert p.shape == (6, 8, 2) and torch.equal(p[5, 1], wt[1, :, 5])
+    w2 = torch.randn(4, 3, 3, 3)
+    p = packing.pack_conv2d(w2)
+    assert p.shape == (9, 8, 4) and torch.equal(p[2 * 3 + 1, 2], w2[:, 2, 2, 1])
+    l = torch.randn(6, 10)
+    p = packing.pack_linear(l)
+    assert p.shape == (1, 16, 6) and torch.equal(p[0, 9], l[:, 9])
+    whh = torch.randn(768, 256), torch.randn(768, 256)
+    pk = packing.pack_gru_whh(whh[0], whh[1], 40, 24, 64)
+    assert pk.numel() == 2 * 768 * 256
+    # streamed region: [half][q][gate][unit][e] with k = half*128 + 64 + 4q + e
+    base = 2 * 40 * 768 + 2 * 24 * 768
+    half, q, gate, unit, e = 1, 3, 2, 17, 1
+    idx = base + ((((half * 16 + q) * 3 + gate) * 256 + unit) * 4 + e)
+    assert pk[idx] == whh[0][gate * 256 + unit, half * 128 + 64 + 4 * q + e]
+
+
+def test_weight_norm_fold_matches_torch():
+    conv = torch.nn.utils.parametrizations.weight_norm(torch.nn.Conv1d(4, 6, 3))
+    g = conv.parametrizations.weight.original0.detach()
+    v = conv.parametrizations.weight.original1.detach()
+    assert torch.allclose(weights.fold_weight_norm(g, v), conv.weight.detach(), atol=1e-7)
+    tr = torch.nn.utils.parametrizations.weight_norm(torch.nn.ConvTranspose1d(4, 6, 4))
+    g = tr.parametrizations.weight.original0.detach()
+    v = tr.parametrizations.weight.original1.detach()
+    assert g.shape == (4, 1, 1)  # dim 0 of a transposed conv is C_in
+    assert torch.allclose(weights.fold_weight_norm(g, v), tr.weight.detach(), atol=1e-7)
+
+
+def test_int16_truncation_and_wav_roundtrip(tmp_path):
+    x = np.array([[0.5, -0.5, 0.99999, -1.0, 1e-5, 0.25]], dtype=np.float32)
+    assert list(audio_io.to_int16(x)[0]) == [16384, -16384, 32767, -32768, 0, 8192]
+    f = str(tmp_path / "a.wav")
+    audio_io.save_wave(x, f)
+    y = audio_io.load_wav(f)
+    assert y.shape == (6,) and np.allclose(y, np.array([16384, -16384, 32767, -32768, 0, 8192]) / 32768.0)
+    with pytest.raises(RuntimeError):
+        audio_io.load_wav(str(tmp_path / "a.flac"))
+
+
+def test_oracle_frontend_length_identity():
+    """96 076 samples -> T = 218 -> T' = 222 -> 97 902 output samples (= the reference's oracle.flac)."""
+    from voicefixer_amd import oracle_frontend
+    g = torch.Generator().manual_seed(0)
+    c = oracle_frontend.wav_to_cond(torch.randn(96076, generator=g).numpy() * 0.1)
+    assert tuple(c.shape) == (1, 128, 222) and 441 * c.shape[-1] == 97902
+    assert c.min() >= -4.0 and c.max() <= 4.0 and (c[..., -4:] == -4.0).all()

@@ -1,0 +1,108 @@
+"""Drop-in API on the MI355X: same calls a user of the reference makes (test/test.py:45-102),
+checked against the CPU oracle / goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import voicefixer_amd  # noqa: E402
+from voicefixer_amd import audio_io, _lib  # noqa: E402
+from conftest import GOLDEN  # noqa: E402
+from oracle import oracle  # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope="module")
+def vf(seeded_states):
+    return voicefixer_amd.VoiceFixer.from_state(*seeded_states)
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)))
+
+
+def test_restore_inmem_matches_golden(vf):
+    g = np.load(os.path.join(GOLDEN, "restore_speech_T51.npz"))
+    for cuda in (False, True):
+        out = vf.restore_inmem(g["wav"], cuda=cuda, mode=0)
+        assert isinstance(out, np.ndarray) and out.dtype == np.float32 and out.shape == g["restored"].shape
+        assert _rms(out, g["restored"]) < 2e-5
+
+
+def test_restore_file_roundtrip(vf, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    fin, fout = str(tmp_path / "in.wav"), str(tmp_path / "out.wav")
+    audio_io.save_wave(g["wav"][None], fin)
+    vf.restore(input=fin, output=fout, cuda=True, mode=0)
+    got = audio_io.load_wav(fout)
+    # the file path quantises input AND output to PCM16: compare with the oracle on the quantised input
+    with torch.no_grad():
+        ref = oracle.restore_inmem(audio_io.load_wav(fin), *_states(vf))
+    want = oracle.to_int16(ref)[0].astype(np.float32) / 32768.0
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1.5 / 32768.0  # at most one PCM step from truncation of ~1e-6 differences
+
+
+def _states(vf):
+    return vf._vocoder._state, vf._restorer_state
+
+
+def test_segmentation_31s_matches_oracle(vf):
+    """> 30 s input: two hard-cut segments (1 323 000 + 44 100 samples), concatenated."""
+    n = 31 * 44100
+    g = torch.Generator().manual_seed(3)
+    t = torch.arange(n, dtype=torch.float64) / 44100.0
+    wav = (0.05 * torch.randn(n, generator=g) + 0.2 * torch.sin(2 * np.pi * 150.0 * t).float()).float().numpy()
+    out = vf.restore_inmem(wav, cuda=True)
+    with torch.no_grad():
+        ref = oracle.restore_inmem(wav, *_states(vf))
+    assert out.shape == ref.shape == (1, n)
+    assert _rms(out, ref) < 2e-5
+
+
+def test_vocoder_forward_and_plugin_hook(vf, seeded_states):
+    voc = voicefixer_amd.Vocoder.from_state(seeded_states[0])
+    g = np.load(os.path.join(GOLDEN, "vocoder_B2_T24.npz"))
+    out = voc.forward(torch.from_numpy(g["mel"]), cuda=False)
+    assert out.device.type == "cpu" and tuple(out.shape) == g["wav"].shape
+    assert _rms(out.numpy(), g["wav"]) < 2e-5
+    assert voc.forward(torch.from_numpy(g["mel"]), cuda=True).is_cuda
+    # our vocoder as a foreign ``your_vocoder_func`` (README.md:232-254): identical to the built-in route
+    gg = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    a = vf.restore_inmem(gg["wav"], cuda=True)
+    b = vf.restore_inmem(gg["wav"], cuda=True, your_vocoder_func=voc)
+    assert _rms(a, b) < 1e-6
+    # a foreign vocoder returning host tensors of a different length is trimmed like the reference does
+    def fake(mel):
+        assert tuple(mel.shape[:2]) == (1, 1) and mel.shape[-1] == 128
+        return torch.zeros(1, 1, 441 * (mel.shape[2] + 6)) + 0.25
+    c = vf.restore_inmem(gg["wav"], cuda=True, your_vocoder_func=fake)
+    assert c.shape == (1, gg["wav"].shape[0]) and np.all(c == 0.25)
+
+
+def test_restore_batch_bucketing(vf):
+    g = torch.Generator().manual_seed(8)
+    wavs = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (20000, 30000, 20000, 25000)]
+    outs = vf.restore_batch(wavs, batch_size=2)
+    for w, o in zip(wavs, outs):
+        assert o.shape == (1, len(w))
+        single = vf.restore_inmem(w, cuda=True)
+        assert _rms(o, single) < 2e-5
+
+
+def test_vocoder_oracle_file(seeded_states, tmp_path):
+    voc = voicefixer_amd.Vocoder.from_state(seeded_states[0])
+    g = torch.Generator().manual_seed(9)
+    fin, fout = str(tmp_path / "in.wav"), str(tmp_path / "o.wav")
+    audio_io.save_wave((0.3 * torch.randn(1, 20000, generator=g)).numpy(), fin)
+    voc.oracle(fin, fout, cuda=True)
+    out = audio_io.load_wav(fout)
+    T = 1 + 20000 // 441
+    assert out.shape == (441 * (T + T % 2 + 4),)
+    from voicefixer_amd import oracle_frontend
+    with torch.no_grad():
+        ref = oracle.vocoder_generator(oracle_frontend.wav_to_cond(audio_io.load_wav(fin)), seeded_states[0])
+    want = oracle.to_int16((ref[0] * 2 ** 15).numpy())[0].astype(np.float32) / 32768.0
+    assert np.abs(out - want).max() <= 1.5 / 32768.0

@@ -1,0 +1,207 @@
+"""Drop-in Python surface of the reference for the restore / vocoder path.
+
+    from voicefixer_amd import VoiceFixer, Vocoder          # == from voicefixer import ...
+
+``VoiceFixer`` mirrors voicefixer/base.py:10-146 and ``Vocoder`` mirrors
+voicefixer/vocoder/base.py:10-77: same constructor behaviour (checkpoint locations and the
+"Error 0"/"Error 1" RuntimeErrors), same method names, argument meaning and return types, the
+``your_vocoder_func`` plugin hook (base.py:126-129) and the 30 s hard-cut segmentation
+(base.py:117-137).  Everything between the waveform going in and the waveform coming out runs
+in libvfx_hip on the MI355X; there is NO CPU implementation behind this API:
+
+  * ``cuda=True``  -> tensors returned on the HIP device where the reference would return CUDA tensors;
+  * ``cuda=False`` -> same kernels, results copied back to host tensors (the reference would
+    compute on the CPU; numerically equivalent within the parity tolerance).  Without a visible
+    device either setting raises -- nothing silently falls back.
+  * ``mode=0`` only.  ``mode=1`` (librosa pre-filter, base.py:87-104) and ``mode=2`` (train-mode
+    BatchNorm/Dropout, exempt from the reference's own check, test/test.py:58) raise
+    NotImplementedError: they are rows of SURVEY.md 8(f), not of the hot path.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import audio_io, engine, weights
+from ._lib import VfxError
+
+SEG_LENGTH = 44100 * 30  # voicefixer/base.py:117
+
+ANALYSIS_CKPT = ".cache/voicefixer/analysis_module/checkpoints/vf.ckpt"
+VOCODER_CKPT = ".cache/voicefixer/synthesis_module/44100/model.ckpt-1490000_trimed.pt"
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("Error: no HIP device found; voicefixer_amd has no CPU fallback "
+                           "(the reference raises 'You set cuda=True but no cuda device found.' here)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _load_vocoder_state(path):
+    ckpt = torch.load(path, map_location="cpu")
+    return ckpt["generator"]  # voicefixer/vocoder/base.py:26-27
+
+
+def _load_restorer_state(path):
+    """vf.ckpt is a flat state dict of restorer.model.VoiceFixer; the engine needs the
+    ``generator.*`` (denoiser + unet) entries (voicefixer/base.py:23-29 key filter)."""
+    sd = torch.load(path, map_location="cpu")
+    if "state_dict" in sd and not any(k.startswith("generator.") for k in sd):
+        sd = sd["state_dict"]
+    out = {k[len("generator."):]: v for k, v in sd.items() if k.startswith("generator.")}
+    voc = {k[len("vocoder.model."):]: v for k, v in sd.items() if k.startswith("vocoder.model.")}
+    return out, (voc or None)  # vf.ckpt may overwrite the vocoder weights
+
+
+class Vocoder(nn.Module):
+    """44.1 kHz TFGAN-style universal vocoder (voicefixer/vocoder/base.py)."""
+
+    def __init__(self, sample_rate=44100, _state=None):
+        super().__init__()
+        if sample_rate != 44100:
+            raise RuntimeError("Error: Vocoder currently only support 44100 samplerate.")  # config.py:28-31
+        self.rate = sample_rate
+        if _state is None:
+            path = os.path.join(os.path.expanduser("~"), VOCODER_CKPT)
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    "Error 1: The checkpoint for synthesis module / vocoder (model.ckpt-1490000_trimed) is not "
+                    "found in ~/.cache/voicefixer/synthesis_module/44100. There is no network in this build; "
+                    "place the Zenodo file there (https://zenodo.org/record/5600188).")
+            _state = _load_vocoder_state(path)
+        self._state = _state
+        self._engine = None
+
+    @classmethod
+    def from_state(cls, state):
+        """Build from an in-memory generator state dict (either weight-norm key style)."""
+        return cls(44100, _state=state)
+
+    def _get_engine(self):
+        if self._engine is None:
+            self._engine = engine.VocoderEngine(self._state, _device())
+        return self._engine
+
+    def forward(self, mel, cuda=False):
+        """mel: [B, 1, T, 128] linear, non-normalised -> [B, 1, 441*(T + T%2 + 4)]."""
+        assert mel.size()[-1] == 128
+        eng = self._get_engine()
+        dev = eng.device
+        m = mel.detach().to(dev, torch.float32)[:, 0].contiguous()
+        T = m.shape[1]
+        wav, L = eng.forward(m, T)
+        out = wav[:, :, :L]
+        return out if cuda else out.cpu()
+
+    __call__ = forward  # usable directly as ``your_vocoder_func`` (with the default cuda=False)
+
+    def oracle(self, fpath, out_path, cuda=False):
+        """wav file -> ground-truth mel (librosa-style STFT + slaney HTK mel, on the host) ->
+        vocoder -> wav file (voicefixer/vocoder/base.py:58-77)."""
+        from . import oracle_frontend
+        wav = audio_io.load_wav(fpath, self.rate, mono=True)
+        cond = oracle_frontend.wav_to_cond(wav)  # (1, 128, T') float32, normalised + padded
+        eng = self._get_engine()
+        c = cond.to(eng.device)
+        Tc = c.shape[-1]
+        buf = torch.empty((1, 128, (Tc + 3) // 4 * 4), device=eng.device)
+        buf[:, :, :Tc] = c
+        wav_re, L = eng.forward_cond(buf, Tc)
+        audio_io.save_wave((wav_re[:, 0, :L] * 2 ** 15).cpu().numpy(), out_path, sample_rate=self.rate)
+
+
+class VoiceFixer(nn.Module):
+    """General speech restoration, inference path (voicefixer/base.py)."""
+
+    def __init__(self, _states=None):
+        super().__init__()
+        if _states is None:
+            path = os.path.join(os.path.expanduser("~"), ANALYSIS_CKPT)
+            if not os.path.exists(path):
+                raise RuntimeError(
+                    "Error 0: The checkpoint for analysis module (vf.ckpt) is not found in "
+                    "~/.cache/voicefixer/analysis_module/checkpoints. There is no network in this build; "
+                    "place the Zenodo file there (https://zenodo.org/record/5600188/files/vf.ckpt).")
+            restorer_state, voc_override = _load_restorer_state(path)
+            vocoder = Vocoder(44100)
+            if voc_override:
+                merged = dict(weights.normalise_vocoder_keys(vocoder._state))
+                merged.update(weights.normalise_vocoder_keys(voc_override))
+                vocoder = Vocoder.from_state(merged)
+        else:
+            vocoder_state, restorer_state = _states
+            vocoder = Vocoder.from_state(vocoder_state)
+        self._vocoder = vocoder
+        self._restorer_state = restorer_state
+        self._pipe = None
+
+    @classmethod
+    def from_state(cls, vocoder_state, restorer_state):
+        """Build from in-memory state dicts (restorer keys without the ``generator.`` prefix)."""
+        return cls(_states=(vocoder_state, restorer_state))
+
+    def _get_pipe(self):
+        if self._pipe is None:
+            dev = _device()
+            self._pipe = engine.Pipeline(self._vocoder._state, self._restorer_state, dev)
+            self._vocoder._engine = self._pipe.vocoder
+        return self._pipe
+
+    def _load_wav(self, path, sample_rate, threshold=0.95):
+        return audio_io.load_wav(path, sample_rate)
+
+    @staticmethod
+    def _check_mode(mode):
+        if mode == 0:
+            return
+        if mode in (1, 2):
+            raise NotImplementedError(
+                "mode=%d is outside the MI355X hot path (mode 1: librosa pre-filter, mode 2: train-mode "
+                "BatchNorm/Dropout); only mode 0 is implemented" % mode)
+        raise ValueError("mode must be 0, 1 or 2")
+
+    @torch.no_grad()
+    def restore_inmem(self, wav_10k, cuda=False, mode=0, your_vocoder_func=None):
+        """wav_10k: float32 numpy (N,) at 44.1 kHz -> float32 numpy (1, N).
+        30 s hard-cut segments, no overlap, concatenated (voicefixer/base.py:117-138)."""
+        self._check_mode(mode)
+        pipe = self._get_pipe()
+        wav = np.asarray(wav_10k, dtype=np.float32)
+        res = []
+        break_point = SEG_LENGTH
+        while break_point < wav.shape[0] + SEG_LENGTH:
+            segment = wav[break_point - SEG_LENGTH: break_point]
+            seg = torch.from_numpy(np.ascontiguousarray(segment))[None].to(pipe.device)
+            res.append(pipe.restore(seg, segment.shape[0], your_vocoder_func))
+            break_point += SEG_LENGTH
+        out = torch.cat(res, -1)
+        return out.cpu().numpy()
+
+    @torch.no_grad()
+    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32):
+        """Batched folder inference (not in the reference, which loops files at B=1,
+        voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i).
+        Utterances are bucketed by length; each 30 s segment index is one batched launch."""
+        pipe = self._get_pipe()
+        order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
+        outs = [None] * len(wavs)
+        i = 0
+        while i < len(order):
+            n = len(wavs[order[i]])
+            grp = [k for k in order[i:i + batch_size] if len(wavs[k]) == n]
+            parts = []
+            for s0 in range(0, n, SEG_LENGTH):
+                seg = np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH] for k in grp])
+                parts.append(pipe.restore(torch.from_numpy(seg).to(pipe.device), seg.shape[1], your_vocoder_func))
+            full = torch.cat(parts, -1).cpu().numpy()
+            for r, k in enumerate(grp):
+                outs[k] = full[r:r + 1]
+            i += len(grp)
+        return outs
+
+    def restore(self, input, output, cuda=False, mode=0, your_vocoder_func=None):
+        wav_10k = self._load_wav(input, sample_rate=44100)
+        out_np_wav = self.restore_inmem(wav_10k, cuda=cuda, mode=mode, your_vocoder_func=your_vocoder_func)
+        audio_io.save_wave(out_np_wav, fname=output, sample_rate=44100)

@@ -1,0 +1,73 @@
+"""Multi-GPU folder inference: one process per GPU (``torch.distributed``; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" for the CPU tests).
+
+The path shards embarrassingly: utterances are independent, so each rank
+restores a contiguous block of the (length-sorted) work list with NO collective in the data
+path.  RCCL is used only for the trivial movement of the batch when the caller holds all
+inputs on rank 0: one scatter of inputs and one gather of outputs per job.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous block of rank ``rank``: sizes differ by at most one, blocks cover [0, n)."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def scatter_utterances(wavs_on_root, n_samples, device, group=None, root=0):
+    """Rank ``root`` holds a float32 tensor (n_utt, n_samples); every rank receives its block
+    (shard_range) as a device tensor.  Point-to-point sends: xGMI is a full mesh, a ring buys
+    nothing for a one-shot fan-out."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    meta = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == root:
+        meta[0] = wavs_on_root.shape[0]
+    dist.broadcast(meta, src=root, group=group)
+    n_utt = int(meta.item())
+    lo, hi = shard_range(n_utt, rank, world)
+    mine = torch.empty((hi - lo, n_samples), dtype=torch.float32, device=device)
+    if rank == root:
+        reqs = []
+        for r in range(world):
+            a, b = shard_range(n_utt, r, world)
+            if r == root:
+                mine.copy_(wavs_on_root[a:b])
+            elif b > a:
+                reqs.append(dist.isend(wavs_on_root[a:b].to(device).contiguous(), dst=r, group=group))
+        for q in reqs:
+            q.wait()
+    elif hi > lo:
+        dist.recv(mine, src=root, group=group)
+    return mine, (lo, hi), n_utt
+
+
+def gather_utterances(mine, n_utt, n_samples, device, group=None, root=0):
+    """Inverse of scatter_utterances: rank ``root`` returns (n_utt, n_samples), others None."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rank == root:
+        out = torch.empty((n_utt, n_samples), dtype=torch.float32, device=device)
+        for r in range(world):
+            a, b = shard_range(n_utt, r, world)
+            if r == root:
+                out[a:b].copy_(mine)
+            elif b > a:
+                buf = torch.empty((b - a, n_samples), dtype=torch.float32, device=device)
+                dist.recv(buf, src=r, group=group)
+                out[a:b].copy_(buf)
+        return out
+    if mine.shape[0] > 0:
+        dist.send(mine.contiguous(), dst=root, group=group)
+    return None
+
+
+def restore_sharded(restore_fn, wavs_on_root, n_samples, device, batch_size=32, group=None, root=0):
+    """scatter -> each rank runs ``restore_fn(batch (b, n_samples)) -> (b, n_samples)`` over its block
+    in batches of ``batch_size`` -> gather on ``root``.  ``restore_fn`` is Pipeline.restore on GPUs."""
+    mine, _, n_utt = scatter_utterances(wavs_on_root, n_samples, device, group, root)
+    outs = [restore_fn(mine[i:i + batch_size]) for i in range(0, mine.shape[0], batch_size)]
+    local = torch.cat(outs, 0) if outs else mine
+    return gather_utterances(local, n_utt, n_samples, device, group, root)
