@@ -65,6 +65,7 @@ struct ConvArgs {
     float pre_slope, post_slope;
     int in_mask, out_mask;  // pitch-1 (e.g. 127) or 0: positions with (l & mask) == mask are structural zeros
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
+    int tpw;                // consecutive L-tiles walked by one FAST workgroup
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -91,8 +92,8 @@ struct StageState {
 // loads, no per-element range logic, no branches.  Boundary tiles run the general instance.
 template <bool FAST, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const ConvArgs& a,
-                                           const float* __restrict__ xb, int xcs, int c0) {
-    const float* __restrict__ xc = xb + (long long)c0 * xcs;
+                                           const float* __restrict__ xb, int xcs, int c0, int lshift) {
+    const float* __restrict__ xc = xb + (long long)c0 * xcs + lshift;
     const float* __restrict__ wc = a.w + (long long)c0 * a.Cout;
 #pragma unroll
     for (int j = 0; j < MAXXV; ++j) {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const C
 template <bool FAST, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, int c0, float* xs,
                                             float* ws, const float* aff, int nxv, int nwv, int xtotal,
-                                            int wtotal, int tid) {
+                                            int wtotal, int tid, int lshift) {
     const int pre_act = a.pre_act;
     const float pre_slope = a.pre_slope;
     const int in_mask = a.in_mask;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                 for (int k = 0; k < 4; ++k) e[k] = vfx_lrelu(fmaf(e[k], sc, sh), pre_slope);
                 if constexpr (!FAST) {
                     // zero padding applies to the ACTIVATED input
-                    const int l = st.x_l[j];
+                    const int l = st.x_l[j] + lshift;
                     const bool cbad = c >= a.Cin;
                     if (a.pad_mode != VFX_PAD_REFLECT) {
 #pragma unroll
@@ -160,7 +161,7 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                 }
             }
             if (in_mask) {
-                const int l = st.x_l[j];
+                const int l = st.x_l[j] + lshift;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     if (((l + k) & in_mask) == in_mask) e[k] = 0.f;
@@ -177,6 +178,92 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
             i = i < wtotal ? i : wtotal - 1;
             *reinterpret_cast<float4*>(ws + 4 * i) = st.wv[j];
         }
+}
+
+// ---- epilogue of one tile: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int BM, int BL, int WGM, int WGL>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BL / WGL / 32], int q0,
+                                              int m0, int b, int wm, int wl, int lo, int hi, int ooff) {
+    constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
+    float* __restrict__ yb = a.y + (long long)b * a.y_bs;
+    const float* __restrict__ rb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
+    const int nbase = m0 + wm * WMT + 4 * hi;
+    if (a.post_act <= VFX_POST_LRELU) {
+        // hot case (no / leaky-ReLU activation): unrolled, 32-bit offsets from the per-batch base, one
+        // 32x32 accumulator tile at a time (sched barriers keep the register footprint of the in-loop
+        // epilogue small: it runs while the next tile's first chunks sit in the staging registers)
+        const float slope = a.post_act == VFX_POST_LRELU ? a.post_slope : 1.f;
+        const int ycs = (int)a.y_cs, yls = (int)a.y_ls, rcs = (int)a.r_cs, rls = (int)a.r_ls;
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const int q = q0 + wl * WLT + j * 32 + lo;
+            const int out = (q >> a.q_shift) * a.o_rs + (q & a.q_mask) * a.o_cs + ooff;
+            const bool ok = q < a.Lq && out >= 0 && out < a.Lout;
+            const bool zero = a.out_mask && ((out & a.out_mask) == a.out_mask);
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                if (ok) {
+                    const int n0 = nbase + i * 32;
+                    const int yo = n0 * ycs + out * yls;
+                    const int ro = n0 * rcs + out * rls;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bq = a.bias ? *reinterpret_cast<const float4*>(a.bias + n0 + 8 * g)
+                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
+                        float v0 = acc[i][j][4 * g + 0] + bq.x, v1 = acc[i][j][4 * g + 1] + bq.y;
+                        float v2 = acc[i][j][4 * g + 2] + bq.z, v3 = acc[i][j][4 * g + 3] + bq.w;
+                        if (rb) {
+                            v0 += rb[ro + (8 * g + 0) * rcs];
+                            v1 += rb[ro + (8 * g + 1) * rcs];
+                            v2 += rb[ro + (8 * g + 2) * rcs];
+                            v3 += rb[ro + (8 * g + 3) * rcs];
+                        }
+                        v0 = v0 > 0.f ? v0 : v0 * slope; v1 = v1 > 0.f ? v1 : v1 * slope;
+                        v2 = v2 > 0.f ? v2 : v2 * slope; v3 = v3 > 0.f ? v3 : v3 * slope;
+                        if (zero) { v0 = 0.f; v1 = 0.f; v2 = 0.f; v3 = 0.f; }
+                        yb[yo + (8 * g + 0) * ycs] = v0;
+                        yb[yo + (8 * g + 1) * ycs] = v1;
+                        yb[yo + (8 * g + 2) * ycs] = v2;
+                        yb[yo + (8 * g + 3) * ycs] = v3;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+            const int q = q0 + wl * WLT + j * 32 + lo;
+            const int out = (q >> a.q_shift) * a.o_rs + (q & a.q_mask) * a.o_cs + ooff;
+            const bool ok = q < a.Lq && out >= 0 && out < a.Lout;
+            const bool zero = a.out_mask && ((out & a.out_mask) == a.out_mask);
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                // transcendental activations (a handful of layers): rolled over the 16 accumulator
+                // registers (uniform dynamic index -> v_movrel) to keep the code small
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r) {
+                    const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (ok) {
+                        float v = acc[i][j][r];
+                        if (a.bias) v += a.bias[n];
+                        if (rb) v += rb[(long long)n * a.r_cs + (long long)out * a.r_ls];
+                        v = vfx_post(v, a.post_act, a.post_slope);
+                        if (zero) v = 0.f;
+                        yb[(long long)n * a.y_cs + (long long)out * a.y_ls] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// exact i / d for 0 <= i < 2^20, 0 < d < 2^12 without the ~40-instruction integer division
+__device__ __forceinline__ int fast_div(int i, int d, float inv) {
+    int q = (int)((float)i * inv);
+    if (q * d > i) --q;
+    if ((q + 1) * d <= i) ++q;
+    return q;
 }
 
 template <int BM, int BL, int WGM, int WGL, int KC, bool FAST>
@@ -219,13 +306,14 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     // the tile are clamped to its last vector: duplicates load and store the same value, which
     // keeps the hot loop free of per-lane predicates.
     StageState<MAXXV, MAXWV> st;
+    const float inv_sv = 1.0f / (float)sv, inv_row = 1.0f / (float)(KC * sv);
 #pragma unroll
     for (int j = 0; j < MAXXV; ++j) {
         int i = tid + 256 * j;
         i = i < xtotal ? i : xtotal - 1;
-        const int s = i / (KC * sv);
+        const int s = fast_div(i, KC * sv, inv_row);
         const int rem = i - s * (KC * sv);
-        const int kc = rem / sv;
+        const int kc = fast_div(rem, sv, inv_sv);
         const int v = rem - kc * sv;
         st.x_kc[j] = kc;
         st.x_l[j] = q0 + pt->seg_org[s] + 4 * v;
@@ -250,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
     const int a_col = wm * WMT + lo;  // column into the weight tile row
     const int b_col = wl * WLT + lo;  // column into the activation tile row
     const int nchunks = (a.Cin + KC - 1) / KC;
@@ -264,74 +353,63 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
         }
         __syncthreads();
     }
-    stage_load<FAST>(st, a, xb, xcs, 0);
-    stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid);
+    // Software pipeline over the K chunks, two steps deep: at the top of step s the registers hold
+    // chunk s+1 (loaded a whole step ago, so the wait is free); they are written to the other LDS
+    // buffer, the loads of chunk s+2 are issued, and only then the MFMAs of chunk s run.  One barrier
+    // per step.  (A multi-tile variant with the epilogue inside this loop was measured SLOWER: its
+    // extra live registers cost the third wave per SIMD, which matters more than the saved prologue.)
+    const int S = nchunks;
+    int ch1 = 1, ch2 = 2;  // chunk held in registers / chunk being loaded at the top of step s
+    constexpr int ti1 = 0, ti2 = 0;
+    stage_load<FAST>(st, a, xb, xcs, 0, 0);
+    stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0);
+    if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0);
     __syncthreads();
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const float* xs = smem + (ch & 1) * bufstride;
+    for (int s = 0; s < S; ++s) {
+        const float* xs = smem + (s & 1) * bufstride;
         const float* ws = xs + a.xs_floats;
 #if !(VFX_ABL & 1)
-        if (ch + 1 < nchunks) stage_load<FAST>(st, a, xb, xcs, (ch + 1) * KC);
+        if (s + 1 < S) {
+            float* nxs = smem + ((s + 1) & 1) * bufstride;
+            stage_write<FAST>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL);
+            if (s + 2 < S) stage_load<FAST>(st, a, xb, xcs, ch2 * KC, ti2 * BL);
+        }
 #endif
 #pragma unroll
         for (int t = 0; t < VFX_MAXT; ++t) {
             if ((t < nt) && !(VFX_ABL & 4)) {
                 const float* xt = xs + tap_lds[t] + b_col;
                 const float* wt = ws + t * (KC * BM) + a_col;
+                // fragments of k-step kk+1 are read from LDS before the MFMAs of k-step kk are issued
+                float af[2][RM], bf[2][RL];
+#pragma unroll
+                for (int i = 0; i < RM; ++i) af[0][i] = wt[hi * BM + i * 32];
+#pragma unroll
+                for (int j = 0; j < RL; ++j) bf[0][j] = xt[hi * segw + j * 32];
 #pragma unroll
                 for (int kk = 0; kk < KC / 2; ++kk) {
-                    float af[RM], bf[RL];
+                    if (kk + 1 < KC / 2) {
 #pragma unroll
-                    for (int i = 0; i < RM; ++i) af[i] = wt[(2 * kk + hi) * BM + i * 32];
+                        for (int i = 0; i < RM; ++i) af[(kk + 1) & 1][i] = wt[(2 * kk + 2 + hi) * BM + i * 32];
 #pragma unroll
-                    for (int j = 0; j < RL; ++j) bf[j] = xt[(2 * kk + hi) * segw + j * 32];
+                        for (int j = 0; j < RL; ++j) bf[(kk + 1) & 1][j] = xt[(2 * kk + 2 + hi) * segw + j * 32];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // keep the next step's LDS reads ahead of these MFMAs
 #pragma unroll
                     for (int i = 0; i < RM; ++i)
 #pragma unroll
                         for (int j = 0; j < RL; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
                 }
             }
         }
-#if !(VFX_ABL & 1)
-        if (ch + 1 < nchunks) {
-            float* nxs = smem + ((ch + 1) & 1) * bufstride;
-            stage_write<FAST>(st, a, (ch + 1) * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid);
-        }
-#endif
 #if !(VFX_ABL & 2)
         __syncthreads();
 #endif
+        ++ch1;
+        ++ch2;
     }
-
-    // ---- epilogue: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    float* __restrict__ yb = a.y + (long long)b * a.y_bs;
-    const float* __restrict__ rb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
-    const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
-#pragma unroll
-    for (int j = 0; j < RL; ++j) {
-        const int q = q0 + wl * WLT + j * 32 + lo;
-        const int out = (q >> a.q_shift) * a.o_rs + (q & a.q_mask) * a.o_cs + ooff;
-        const bool ok = q < a.Lq && out >= 0 && out < a.Lout;
-        const bool zero = a.out_mask && ((out & a.out_mask) == a.out_mask);
-#pragma unroll
-        for (int i = 0; i < RM; ++i) {
-            // rolled over the 16 accumulator registers (uniform dynamic index -> v_movrel),
-            // so the activation code is emitted RM*RL times instead of 16*RM*RL times
-#pragma unroll 1
-            for (int r = 0; r < 16; ++r) {
-                const int n = m0 + wm * WMT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (ok) {
-                    float v = acc[i][j][r];
-                    if (a.bias) v += a.bias[n];
-                    if (rb) v += rb[(long long)n * a.r_cs + (long long)out * a.r_ls];
-                    v = vfx_post(v, a.post_act, a.post_slope);
-                    if (zero) v = 0.f;
-                    yb[(long long)n * a.y_cs + (long long)out * a.y_ls] = v;
-                }
-            }
-        }
-    }
+    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff);
 }
 
 // --------------------------------------------------------------------------------------
@@ -399,7 +477,8 @@ template <int BM, int BL, int WGM, int WGL, int KC>
 static int launch_cfg(const ConvArgs& a, int ntiles, int gy, int gz, size_t lds, hipStream_t s) {
     const int nfast = a.tile_hi - a.tile_lo;
     int rc = VFX_OK;
-    if (nfast > 0) rc = launch_one<BM, BL, WGM, WGL, KC, true>(a, dim3(nfast, gy, gz), lds, s);
+    if (nfast > 0)
+        rc = launch_one<BM, BL, WGM, WGL, KC, true>(a, dim3((nfast + a.tpw - 1) / a.tpw, gy, gz), lds, s);
     if (rc == VFX_OK && ntiles - nfast > 0)
         rc = launch_one<BM, BL, WGM, WGL, KC, false>(a, dim3(ntiles - nfast, gy, gz), lds, s);
     return rc;
@@ -552,6 +631,12 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         if (tlo > thi || Cin % KC != 0) { tlo = 0; thi = 0; }
         a.tile_lo = tlo;
         a.tile_hi = thi;
+    }
+    {
+        // tiles per FAST workgroup: as many as keeps >= ~1024 workgroups in flight, at most 8
+        const long long nwg1 = (long long)(a.tile_hi - a.tile_lo) * (nphase * Cout / tc.BM) * B;
+        (void)nwg1;
+        a.tpw = 1;  // multi-tile workgroups measured slower (register pressure), see the kernel comment
     }
     const int gy = nphase * Cout / tc.BM;
 #define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                    \
