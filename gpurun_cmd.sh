@@ -1,2 +1,6 @@
-python -m pytest tests/test_ops_gpu.py -x -q -m gpu 2>&1 | tail -2
-python tools/conv_bench.py --batch 8 res4_d1 res4_d27 res4_d2187 res3_d1 res2_d1 res2_d243 res1_d1 res1_d729 pre_k7 cond up1 up2 up3 up4 unet1 unet2 unet3 unet4 unet5 gru_proj 2>&1 | grep -v amdgpu.ids
+for B in 1 4 32; do
+python bench.py --steps 3 --warmup 1 --batch $B --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('B=%d  %.1f xRT  %.1f ms/step  path %.1f TF  dom %s %.1f TF  conv-share %.2f' % (d['config']['batch_per_gpu'], d['value'], d['ms_per_step'], d['path_tflops'], d['roofline']['kernel'], d['roofline']['achieved'], d['roofline']['all_conv_kernels']['time_share_of_step']))"
+done

@@ -20,6 +20,7 @@
 // the MFMAs of the current one run, one barrier per chunk; <= 80 KB LDS and <= 256 VGPR
 // keep two workgroups per CU so one stages while the other computes.
 #include "vfx_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -33,6 +34,19 @@
 #define VFX_MAXT 9
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#if VFX_ABL & 8
+// development: per-phase cycle totals (wave 0 of every workgroup), read back with vfx_debug_read
+__device__ unsigned long long g_dbg[8];
+extern "C" int vfx_debug_read(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 8);
+    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
+    return 0;
+}
+#define DBG_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#else
+#define DBG_T(v)
+#endif
 
 // per-phase tap tables live in device memory (cached per distinct conv geometry): a by-value
 // kernarg array indexed per lane makes the compiler hold the whole table in SGPRs.
@@ -365,16 +379,28 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0);
     if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0);
     __syncthreads();
+#if VFX_ABL & 8
+    unsigned long long d_write = 0, d_load = 0, d_mfma = 0, d_bar = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
     for (int s = 0; s < S; ++s) {
         const float* xs = smem + (s & 1) * bufstride;
         const float* ws = xs + a.xs_floats;
+        DBG_T(t0);
 #if !(VFX_ABL & 1)
         if (s + 1 < S) {
             float* nxs = smem + ((s + 1) & 1) * bufstride;
             stage_write<FAST>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL);
+#if VFX_ABL & 8
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        }
+        DBG_T(t1);
+        if (s + 1 < S) {
             if (s + 2 < S) stage_load<FAST>(st, a, xb, xcs, ch2 * KC, ti2 * BL);
         }
 #endif
+        DBG_T(t2);
 #pragma unroll
         for (int t = 0; t < VFX_MAXT; ++t) {
             if ((t < nt) && !(VFX_ABL & 4)) {
@@ -403,13 +429,32 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
                 }
             }
         }
+#if VFX_ABL & 8
+        asm volatile("s_nop 0" ::: "memory");
+#endif
+        DBG_T(t3);
 #if !(VFX_ABL & 2)
         __syncthreads();
+#endif
+        DBG_T(t4);
+#if VFX_ABL & 8
+        d_write += t1 - t0; d_load += t2 - t1; d_mfma += t3 - t2; d_bar += t4 - t3;
 #endif
         ++ch1;
         ++ch2;
     }
+#if VFX_ABL & 8
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff);
+#if VFX_ABL & 8
+    if (tid == 0 && FAST) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_dbg[0], d_write); atomicAdd(&g_dbg[1], d_load); atomicAdd(&g_dbg[2], d_mfma);
+        atomicAdd(&g_dbg[3], d_bar); atomicAdd(&g_dbg[4], t_loop - t_start); atomicAdd(&g_dbg[5], t_end - t_loop);
+        atomicAdd(&g_dbg[6], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)S);
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------
@@ -611,7 +656,12 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     a.tab = device_tables(tb);
     if (!a.tab) return VFX_EINVAL;
     a.ws_floats = maxnt * KC * tc.BM;
-    const size_t lds = (2ull * (a.xs_floats + a.ws_floats) + 2ull * a.CinPad) * sizeof(float);
+    size_t lds = (2ull * (a.xs_floats + a.ws_floats) + 2ull * a.CinPad) * sizeof(float);
+    {
+        // development knob: VFX_LDS_MIN_KB pads the request to limit workgroups per CU (occupancy studies)
+        static const long pad_kb = getenv("VFX_LDS_MIN_KB") ? atol(getenv("VFX_LDS_MIN_KB")) : 0;
+        if (pad_kb > 0 && lds < (size_t)pad_kb * 1024) lds = (size_t)pad_kb * 1024;
+    }
     if (lds > 160 * 1024) return VFX_ERANGE;
 
     g_last_tile = tc.BM * 100000 + tc.BL * 100 + KC;
