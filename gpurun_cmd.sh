@@ -1,4 +1,5 @@
-for B in 1 4 32; do
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5
+for B in 1 32; do
 python bench.py --steps 3 --warmup 1 --batch $B --no-cpu-baseline 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

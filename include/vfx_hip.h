@@ -41,6 +41,10 @@ typedef void* vfx_stream_t; /* hipStream_t */
 typedef struct {
     void* ptr;
     int64_t bstride, cstride, lstride; /* element strides */
+    int64_t guard; /* INPUT tensors of the conv family: number of elements that may be READ (contents
+                      arbitrary, they are masked) before l = 0 and after l = L-1 of every (b, c) row.
+                      With a guard >= the largest tap offset + 8 every tile takes the branch-free
+                      interior kernel; 0 is always legal (boundary tiles then run the general kernel). */
 } vfx_tensor;
 
 /* pre-activation applied to the INPUT while it is staged into LDS */
@@ -146,16 +150,17 @@ int vfx_tm_to_cm_f32(const float* src, float* dst, int B, int T, int C, int64_t 
                      int64_t dst_cstride, vfx_stream_t stream);
 
 /* clean = mask*mel; x = log10(max(clean,1e-8)); U = [log10(max(mel,1e-8)), x] written as the
- * UNet input (B,2,Tp,128-pitch) with bin 127 and rows >= T zero.  mask is channel-major
+ * UNet input (B,nch>=2,Tp*128) pitch map (channels >= 2 are zero filler so the first conv has no
+ * channel tail) with bin 127 and rows >= T zero.  mask is channel-major
  * (B,128,*).  Replaces voicefixer/restorer/model.py:105-108 + model_kqq_bn.py:145-151. */
-int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, float* unet_in, int B, int T,
-                       int Tp, vfx_stream_t stream);
+int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, const vfx_tensor* unet_in, int nch,
+                       int B, int T, int Tp, vfx_stream_t stream);
 
 /* logmel = unet_out + x, x = log10(max(mask*mel,1e-8)); the UNet never sees mel bin 127 and
  * emits 0 there (model_kqq_bn.py:151,177), so logmel[...,127] = x[...,127] is recomputed from
  * mel and mask.  denoised = 10^min(logmel,5).  Both outputs are (B,T,128) frame-major.
  * Replaces restorer/model.py:112 + voicefixer/base.py:125 (from_log). */
-int vfx_unet_output_f32(const float* unet_out, const float* unet_in, const float* mel,
+int vfx_unet_output_f32(const vfx_tensor* unet_out, const vfx_tensor* unet_in, const float* mel,
                         const vfx_tensor* mask, float* logmel, float* denoised, int B, int T,
                         int Tp, vfx_stream_t stream);
 

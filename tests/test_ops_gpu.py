@@ -102,6 +102,26 @@ def test_conv1d(case):
     assert torch.isnan(yd[:, :, L:]).all()  # nothing written past L
 
 
+def test_conv1d_guarded_input_all_interior():
+    """With a guard band every tile (also the first/last) runs the interior kernel; the guard
+    holds NaN to prove that whatever is read there is masked."""
+    B, Cin, Cout, L, k, dil = 2, 64, 64, 1000, 3, 81
+    x = _rand((B, Cin, L), 41)
+    w = _rand((Cout, Cin, k), 42, (Cin * k) ** -0.5)
+    bias = _rand((Cout,), 43, 0.1)
+    ref = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.01), w, bias, dilation=dil, padding=dil), 0.01)
+    xd = ops.guarded(B, Cin, L, dil + 264, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xd[:, :, :L] = x.to(DEV)
+    yd = torch.full((B, Cout, 1000), float("nan"), device=DEV)
+    act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
+    before = _lib.lib().vfx_launch_count()
+    ops.conv1d(xd, packing.pack_conv1d(w).to(DEV), bias.to(DEV), yd, L, k, dil, 0, act)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1  # one grid: no boundary launch
+    _close(yd, ref, 2e-5)
+
+
 def test_linear_transposed_output():
     """Linear as conv k=1 with a frame-major output view (B,T,out) -- used for GRU x-projections."""
     B, T, Cin, Cout = 2, 101, 512, 1536
@@ -323,18 +343,18 @@ def test_unet_input_output_and_post():
     mel_d = mel[:, 0].contiguous().to(DEV)
     mask_cm = torch.zeros((B, 128, 40), device=DEV)
     mask_cm[:, :, :T] = mask[:, 0].transpose(1, 2).to(DEV)
-    u = torch.full((B, 2, Tp, 128), float("nan"), device=DEV)
+    u = torch.full((B, 4, Tp * 128), float("nan"), device=DEV)  # 2 real + 2 filler channels
     ops.unet_input(mel_d, mask_cm, u, T, Tp)
     torch.cuda.synchronize()
-    got = u.cpu()
-    _close(got[:, :, :T, :127], u_ref[..., :127], 1e-6)
-    assert (got[:, :, T:, :] == 0).all() and (got[..., 127] == 0).all()
+    got = u.cpu().reshape(B, 4, Tp, 128)
+    _close(got[:, :2, :T, :127], u_ref[..., :127], 1e-6)
+    assert (got[:, :2, T:, :] == 0).all() and (got[:, :2, :, 127] == 0).all() and (got[:, 2:] == 0).all()
 
     uo = _rand((B, 1, Tp, 128), 36)
     uo[..., 127] = 0
     logmel = torch.empty((B, T, 128), device=DEV)
     den = torch.empty((B, T, 128), device=DEV)
-    ops.unet_output(uo.to(DEV), u, mel_d, mask_cm, logmel, den, T, Tp)
+    ops.unet_output(uo.reshape(B, 1, Tp * 128).to(DEV), u, mel_d, mask_cm, logmel, den, T, Tp)
     torch.cuda.synchronize()
     ref_lm = uo[:, 0, :T] + x[:, 0]
     _close(logmel, ref_lm, 1e-5)

@@ -19,7 +19,7 @@ class VfxError(RuntimeError):
 
 class vfx_tensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bstride", C.c_int64), ("cstride", C.c_int64),
-                ("lstride", C.c_int64)]
+                ("lstride", C.c_int64), ("guard", C.c_int64)]
 
 
 class vfx_act(C.Structure):
@@ -50,8 +50,8 @@ SIGNATURES = {
     "vfx_frontend_init": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "vfx_stft_mel_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
     "vfx_tm_to_cm_f32": (_I, [_P, _P, _I, _I, _I, C.c_int64, C.c_int64, _P]),
-    "vfx_unet_input_f32": (_I, [_P, _T, _P, _I, _I, _I, _P]),
-    "vfx_unet_output_f32": (_I, [_P, _P, _P, _T, _P, _P, _I, _I, _I, _P]),
+    "vfx_unet_input_f32": (_I, [_P, _T, _T, _I, _I, _I, _I, _P]),
+    "vfx_unet_output_f32": (_I, [_T, _T, _P, _T, _P, _P, _I, _I, _I, _P]),
     "vfx_gru_bidir_f32": (_I, [_P, _P, _P, _T, _I, _I, _P]),
     "vfx_gru_layout": (None, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "vfx_mel_to_cond_f32": (_I, [_P, _T, _I, _I, _P]),

@@ -147,7 +147,7 @@ __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const C
 template <bool FAST, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, int c0, float* xs,
                                             float* ws, const float* aff, int nxv, int nwv, int xtotal,
-                                            int wtotal, int tid, int lshift) {
+                                            int wtotal, int tid, int lshift, bool range_mask) {
     const int pre_act = a.pre_act;
     const float pre_slope = a.pre_slope;
     const int in_mask = a.in_mask;
@@ -172,6 +172,15 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                         for (int k = 0; k < 4; ++k)
                             if (l + k < 0 || l + k >= a.Lin || cbad) e[k] = 0.f;
                     }
+                }
+            }
+            if constexpr (FAST) {
+                // tile reaches into the caller's guard band: whatever was read outside [0, Lin) is padding
+                if (range_mask) {
+                    const int l = st.x_l[j] + lshift;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (l + k < 0 || l + k >= a.Lin) e[k] = 0.f;
                 }
             }
             if (in_mask) {
@@ -376,7 +385,15 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     int ch1 = 1, ch2 = 2;  // chunk held in registers / chunk being loaded at the top of step s
     constexpr int ti1 = 0, ti2 = 0;
     stage_load<FAST>(st, a, xb, xcs, 0, 0);
-    stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0);
+    // does any staged vector of this tile leave [0, Lin)?  (uniform; only possible with a guard band)
+    bool range_mask = false;
+    if constexpr (FAST) {
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int o = q0 + __builtin_amdgcn_readfirstlane(pt->seg_org[sg]);
+            range_mask |= (o < 0) || (o + segw > a.Lin);
+        }
+    }
+    stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
     if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0);
     __syncthreads();
 #if VFX_ABL & 8
@@ -390,7 +407,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
 #if !(VFX_ABL & 1)
         if (s + 1 < S) {
             float* nxs = smem + ((s + 1) & 1) * bufstride;
-            stage_write<FAST>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL);
+            stage_write<FAST>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL,
+                              range_mask);
 #if VFX_ABL & 8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -674,8 +692,11 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
                 seg_lo = tb.ph[p].seg_org[sg] < seg_lo ? tb.ph[p].seg_org[sg] : seg_lo;
                 seg_hi = tb.ph[p].seg_org[sg] > seg_hi ? tb.ph[p].seg_org[sg] : seg_hi;
             }
-        int tlo = seg_lo < 0 ? (-seg_lo + tc.BL - 1) / tc.BL : 0;
-        const long long room = (long long)Lin - seg_hi - a.segw;
+        // loads are safe inside [-guard, Lin + guard); values outside [0, Lin) are masked in the kernel
+        const long long g = (x->guard > 0 && pad_mode != VFX_PAD_REFLECT) ? x->guard : 0;
+        const long long need_lo = -(long long)seg_lo - g;  // q0 >= need_lo
+        int tlo = need_lo > 0 ? (int)((need_lo + tc.BL - 1) / tc.BL) : 0;
+        const long long room = (long long)Lin + g - seg_hi - a.segw;
         int thi = room >= 0 ? (int)(room / tc.BL) + 1 : 0;
         if (thi > ntiles) thi = ntiles;
         if (tlo > thi || Cin % KC != 0) { tlo = 0; thi = 0; }

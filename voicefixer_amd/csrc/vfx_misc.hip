@@ -138,8 +138,8 @@ extern "C" int vfx_tm_to_cm_f32(const float* src, float* dst, int B, int T, int 
 // UNet input: U = [log10(max(mel,1e-8)), log10(max(mask*mel,1e-8))] on (Tp, 128-pitch)
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ mel, const float* __restrict__ mask,
-                                                         long long m_bs, long long m_cs, float* __restrict__ u, int T,
-                                                         int Tp) {
+                                                         long long m_bs, long long m_cs, float* __restrict__ u,
+                                                         long long u_bs, long long u_cs, int nch, int T, int Tp) {
     // block = 32 frames x 128 bins; mask is channel-major so it goes through an LDS transpose
     __shared__ float tile[128][33];
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict
     }
     __syncthreads();
     const int c = tid & 127;
-    float* u0 = u + ((long long)b * 2 + 0) * Tp * 128;
-    float* u1 = u + ((long long)b * 2 + 1) * Tp * 128;
+    float* u0 = u + (long long)b * u_bs;
+    float* u1 = u0 + u_cs;
     for (int r = tid >> 7; r < 32; r += 2) {
         const int t = t0 + r;
         if (t >= Tp) break;
@@ -166,24 +166,28 @@ __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict
         }
         u0[(long long)t * 128 + c] = a0;
         u1[(long long)t * 128 + c] = a1;
+        for (int ch = 2; ch < nch; ++ch) u0[ch * u_cs + (long long)t * 128 + c] = 0.f;  // zero filler channels
     }
 }
 
-extern "C" int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, float* unet_in, int B, int T, int Tp,
-                                  vfx_stream_t stream) {
-    if (!mel || !mask || !unet_in || B <= 0 || T <= 0 || Tp < T || (Tp & 63) || B > 65535) return VFX_EINVAL;
-    if (mask->lstride != 1) return VFX_EALIGN;
+extern "C" int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, const vfx_tensor* unet_in, int nch, int B,
+                                  int T, int Tp, vfx_stream_t stream) {
+    if (!mel || !mask || !unet_in || !unet_in->ptr || nch < 2 || B <= 0 || T <= 0 || Tp < T || (Tp & 63) || B > 65535)
+        return VFX_EINVAL;
+    if (mask->lstride != 1 || unet_in->lstride != 1) return VFX_EALIGN;
     dim3 grid((Tp + 31) / 32, B);
     hipLaunchKernelGGL(unet_input_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel, (const float*)mask->ptr,
-                       mask->bstride, mask->cstride, unet_in, T, Tp);
+                       mask->bstride, mask->cstride, (float*)unet_in->ptr, unet_in->bstride, unet_in->cstride, nch, T,
+                       Tp);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
 
 // logmel = unet_out + x.  The UNet never sees bin 127 (pad column of the pitch layout) and
 // emits 0 there, so x[...,127] = log10(max(mask*mel,1e-8)) is recomputed from mel and mask.
-__global__ __launch_bounds__(256) void unet_output_kernel(const float* __restrict__ uo, const float* __restrict__ ui,
-                                                          const float* __restrict__ mel,
+__global__ __launch_bounds__(256) void unet_output_kernel(const float* __restrict__ uo, long long uo_bs,
+                                                          const float* __restrict__ ui, long long ui_bs,
+                                                          long long ui_cs, const float* __restrict__ mel,
                                                           const float* __restrict__ mask, long long m_bs,
                                                           long long m_cs, float* __restrict__ logmel,
                                                           float* __restrict__ den, int T, int Tp) {
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(256) void unet_output_kernel(const float* __restric
     const int t = (int)(i >> 7), c = (int)(i & 127);
     float x, o;
     if (c < 127) {
-        x = ui[((long long)b * 2 + 1) * Tp * 128 + i];
-        o = uo[(long long)b * Tp * 128 + i];
+        x = ui[(long long)b * ui_bs + ui_cs + i];
+        o = uo[(long long)b * uo_bs + i];
     } else {
         const float m = mel[((long long)b * T + t) * 128 + 127];
         const float k = mask[(long long)b * m_bs + 127 * m_cs + t];
@@ -206,13 +210,15 @@ __global__ __launch_bounds__(256) void unet_output_kernel(const float* __restric
     den[(long long)b * T * 128 + i] = exp10f(fminf(lm, 5.f));
 }
 
-extern "C" int vfx_unet_output_f32(const float* unet_out, const float* unet_in, const float* mel,
+extern "C" int vfx_unet_output_f32(const vfx_tensor* unet_out, const vfx_tensor* unet_in, const float* mel,
                                     const vfx_tensor* mask, float* logmel, float* denoised, int B, int T, int Tp,
                                     vfx_stream_t stream) {
-    if (!unet_out || !unet_in || !mel || !mask || !logmel || !denoised || B <= 0 || T <= 0 || Tp < T || B > 65535)
+    if (!unet_out || !unet_in || !unet_out->ptr || !unet_in->ptr || !mel || !mask || !logmel || !denoised || B <= 0 ||
+        T <= 0 || Tp < T || B > 65535)
         return VFX_EINVAL;
     dim3 grid((unsigned)(((long long)T * 128 + 255) / 256), B);
-    hipLaunchKernelGGL(unet_output_kernel, grid, dim3(256), 0, (hipStream_t)stream, unet_out, unet_in, mel,
+    hipLaunchKernelGGL(unet_output_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const float*)unet_out->ptr,
+                       unet_out->bstride, (const float*)unet_in->ptr, unet_in->bstride, unet_in->cstride, mel,
                        (const float*)mask->ptr, mask->bstride, mask->cstride, logmel, denoised, T, Tp);
     VFX_LAUNCHED();
     return vfx_last_error();

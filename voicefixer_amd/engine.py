@@ -29,6 +29,17 @@ def _up4(n):
     return (n + 3) // 4 * 4
 
 
+# Guard bands (readable slack around every row of a conv INPUT, see include/vfx_hip.h): with a
+# guard >= largest tap offset + one tile (256) + 8 every tile of a launch runs the branch-free
+# interior kernel; only reflect-padded and channel-tail launches still need the general one.
+G_TILE = 256 + 8
+G_DIL = 3 ** 7 + G_TILE  # largest ResStack dilation
+
+
+def _rows(B, Cn, L, guard, dev):
+    return ops.guarded(B, Cn, L, guard, dev)
+
+
 def _dev(t, device):
     return t.contiguous().float().to(device)
 
@@ -74,9 +85,8 @@ class VocoderEngine:
         """cond: device (B,128,>=Tc) channel-major.  Returns (wav buffer (B,1,Lp), L = 441*Tc)."""
         B = cond.shape[0]
         dev = cond.device
-        Lp = _up4(Tc)
-        a = torch.empty((B, weights.COND_CHANNELS, Lp), device=dev)
-        b = torch.empty((B, weights.COND_CHANNELS, Lp), device=dev)
+        a = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev)
+        b = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev)
         x = cond
         for i, (w, bias) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
@@ -85,7 +95,7 @@ class VocoderEngine:
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
         # pre: ReflectionPad1d(3) + Conv1d k7 + LeakyReLU(0.2); the next UpsampleNet's x+sin(x) is fused here
-        h = torch.empty((B, weights.VOC_CHANNELS, Lp), device=dev)
+        h = _rows(B, weights.VOC_CHANNELS, Tc, G_TILE, dev)
         ops.conv1d(x, self.pre[0], self.pre[1], h, Tc, 7, 1, PAD_REFLECT, self.act_pre)
         L = Tc
         c = weights.VOC_CHANNELS
@@ -93,8 +103,8 @@ class VocoderEngine:
         for j, (s, upw, layers) in enumerate(self.stages):
             Lo = L * s
             c //= 2
-            xs = torch.empty((B, c, _up4(Lo)), device=dev)
-            ys = torch.empty((B, c, _up4(Lo)), device=dev)
+            xs = _rows(B, c, Lo, G_DIL, dev)
+            ys = _rows(B, c, Lo, G_TILE, dev)
             ops.convtr1d(h, upw[0], upw[1], xs, L, s, self.act_none)
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
@@ -114,7 +124,7 @@ class VocoderEngine:
         """mel: device (B,T,128) linear, non-normalised (Vocoder.forward semantics)."""
         B = mel.shape[0]
         Tc = T + T % 2 + 4
-        cond = torch.empty((B, weights.N_MELS, _up4(Tc)), device=mel.device)
+        cond = _rows(B, weights.N_MELS, Tc, G_TILE, mel.device)
         ops.mel_to_cond(mel, cond, T)
         return self.forward_cond(cond, Tc)
 
@@ -122,11 +132,17 @@ class VocoderEngine:
 class _ConvBlock:
     """ConvBlockRes (restorer/modules.py:7-76) with bn2 folded into conv1."""
 
-    def __init__(self, sd, p, device):
+    def __init__(self, sd, p, device, pad_cin=None):
         s1, sh1 = weights.bn_affine(sd, p + ".bn1")
         s2, sh2 = weights.bn_affine(sd, p + ".bn2")
         w1 = sd[p + ".conv1.weight"].float() * s2.reshape(-1, 1, 1, 1)
         self.cin = w1.shape[1]
+        if pad_cin is not None and pad_cin > self.cin:
+            # zero filler input channels (packed weights are zero-padded to 8 anyway): scale 1, shift 0
+            extra = pad_cin - self.cin
+            s1 = torch.cat([s1, torch.ones(extra)])
+            sh1 = torch.cat([sh1, torch.zeros(extra)])
+            self.cin = pad_cin
         self.cout = w1.shape[0]
         self.w1 = _dev(packing.pack_conv2d(w1), device)
         self.b1 = _dev(sh2, device)
@@ -206,7 +222,8 @@ class RestorerEngine:
 
         self.enc = []
         for b in range(1, 7):
-            self.enc.append([_ConvBlock(sd, "unet.encoder_block%d.conv_block%d" % (b, k), device)
+            self.enc.append([_ConvBlock(sd, "unet.encoder_block%d.conv_block%d" % (b, k), device,
+                                        pad_cin=8 if (b == 1 and k == 1) else None)
                              for k in (1, 2, 3, 4)])
         self.center = _ConvBlock(sd, "unet.conv_block7", device)
         self.dec = []
@@ -225,20 +242,20 @@ class RestorerEngine:
         """mel (B,T,128) -> mask channel-major (B,128,Tp4)."""
         B, dev = mel.shape[0], mel.device
         Tp4 = _up4(T)
-        x0 = torch.empty((B, 128, Tp4), device=dev)
+        x0 = _rows(B, 128, T, G_TILE, dev)
         ops.tm_to_cm(mel, x0, T, 128)
-        x1 = torch.empty((B, 256, Tp4), device=dev)
+        x1 = _rows(B, 256, T, G_TILE, dev)
         ops.conv1d(x0, self.l1[0], self.l1[1], x1, T, 1, act=self.act_relu)
-        x = torch.empty((B, 512, Tp4), device=dev)
+        x = _rows(B, 512, T, G_TILE, dev)
         ops.conv1d(x1, self.l2[0], self.l2[1], x, T, 1, act=self.act_relu)
         gi = torch.empty((B, T, 1536), device=dev)
         for layers in self.grus:
             for (wih, bih, whh, bhh) in layers:
                 ops.conv1d(x, wih, bih, gi.transpose(1, 2), T, 1)
-                y = torch.empty((B, 512, Tp4), device=dev)
+                y = _rows(B, 512, T, G_TILE, dev)
                 ops.gru_bidir(gi, whh, bhh, y, T)
                 x = y
-        x3 = torch.empty((B, 512, Tp4), device=dev)
+        x3 = _rows(B, 512, T, G_TILE, dev)
         ops.conv1d(x, self.l3[0], self.l3[1], x3, T, 1, act=self.act_l3)
         mask = torch.empty((B, 128, Tp4), device=dev)
         ops.conv1d(x3, self.l4[0], self.l4[1], mask, T, 1, act=self.act_sigmoid)
@@ -253,22 +270,23 @@ class RestorerEngine:
         H, lp = Tp, 7
         for blocks in self.enc:
             cout = blocks[0].cout
-            HP = _up4(H << lp)  # channel stride must stay a multiple of 4 floats (deepest level: H*P = 2)
-            cat = torch.empty((B, 2 * cout, HP), device=dev)
+            HP = H << lp
+            G = (1 << lp) + 1 + G_TILE
+            cat = _rows(B, 2 * cout, HP, G, dev)
             skip = cat[:, cout:]
-            a = torch.empty((B, cout, HP), device=dev)
-            y1 = torch.empty((B, cout, HP), device=dev)
+            a = _rows(B, cout, HP, G, dev)
+            y1 = _rows(B, cout, HP, G, dev)
             blocks[0].run(x, y1, a, H, lp)
             blocks[1].run(a, y1, a, H, lp)
             blocks[2].run(a, y1, a, H, lp)
             blocks[3].run(a, y1, skip, H, lp)
             cats.append((cat, H, lp))
-            pooled = torch.empty((B, cout, _up4((H // 2) << (lp - 1))), device=dev)
+            pooled = _rows(B, cout, (H // 2) << (lp - 1), (1 << (lp - 1)) + 1 + G_TILE, dev)
             ops.avgpool2x2(skip, pooled, H, lp)
             x = pooled
             H //= 2
             lp -= 1
-        y1 = torch.empty_like(x)
+        y1 = _rows(B, x.shape[1], H << lp, (1 << lp) + 1 + G_TILE, dev)
         self.center.run(x, y1, x, H, lp)
         for (wt, act, blocks) in self.dec:
             cat, Hs, lps = cats.pop()
@@ -276,9 +294,10 @@ class RestorerEngine:
             assert Hs == 2 * H and lps == lp + 1
             ops.convtr2d_3x3s2(x, wt, cat[:, :cout], H, lp, act)
             H, lp = Hs, lps
-            HP = _up4(H << lp)
-            a = torch.empty((B, cout, HP), device=dev)
-            y1 = torch.empty((B, cout, HP), device=dev)
+            HP = H << lp
+            G = (1 << lp) + 1 + G_TILE
+            a = _rows(B, cout, HP, G, dev)
+            y1 = _rows(B, cout, HP, G, dev)
             blocks[0].run(cat, y1, a, H, lp)
             for blk in blocks[1:]:
                 blk.run(a, y1, a, H, lp)
@@ -292,7 +311,7 @@ class RestorerEngine:
         B, dev = mel.shape[0], mel.device
         Tp = (T + 63) // 64 * 64
         mask = self.denoiser(mel, T)
-        u = torch.empty((B, 2, Tp * 128), device=dev)
+        u = _rows(B, 8, Tp * 128, 128 + 1 + G_TILE, dev)  # 2 real + 6 zero channels: no channel tail
         ops.unet_input(mel, mask, u, T, Tp)
         uo = self.unet(u, Tp)
         logmel = torch.empty((B, T, 128), device=dev)
@@ -300,7 +319,7 @@ class RestorerEngine:
         ops.unet_output(uo, u, mel, mask, logmel, den, T, Tp)
         if debug is not None:
             debug["mask"] = mask[:, :, :T]
-            debug["unet_out"] = uo.reshape(B, Tp, 128)[:, :T]
+            debug["unet_out"] = uo[:, 0, :Tp * 128].reshape(B, Tp, 128)[:, :T]
         return logmel, den
 
 

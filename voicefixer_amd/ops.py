@@ -26,9 +26,22 @@ def _need_cuda(*ts):
 
 
 def tdesc(t):
-    """vfx_tensor for a (B, C, L) tensor view (any strides; element units)."""
+    """vfx_tensor for a (B, C, L) tensor view (any strides; element units).  Views created by
+    ``guarded()`` carry a ``_vfx_guard`` attribute: readable slack on both sides of every row."""
     assert t.dim() == 3 and t.dtype == torch.float32
-    return vfx_tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+    return vfx_tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), getattr(t, "_vfx_guard", 0))
+
+
+def guarded(B, Cn, L, guard, device):
+    """(B, C, Lp) view (Lp = L rounded up to 4) with ``guard`` readable elements before and after every
+    row; the conv kernels mask whatever they read there, so the slack is never initialised."""
+    guard = (guard + 3) // 4 * 4
+    Lp = (L + 3) // 4 * 4
+    buf = torch.empty((B, Cn, guard + Lp + guard), device=device)
+    v = buf[:, :, guard:guard + Lp]
+    v._vfx_guard = guard
+    v._vfx_base = buf  # keep the allocation alive
+    return v
 
 
 def _ptr(t):
@@ -186,16 +199,17 @@ def tm_to_cm(src, dst, T, Cn):
 
 
 def unet_input(mel, mask, unet_in, T, Tp):
+    """unet_in: (B, nch >= 2, >= Tp*128) view; channels >= 2 are written as zero."""
     _need_cuda(mel, mask, unet_in)
-    md = tdesc(mask)
-    check(_lib.lib().vfx_unet_input_f32(_ptr(mel), C.byref(md), _ptr(unet_in), mel.shape[0], T, Tp, _stream()),
-          "vfx_unet_input_f32")
+    md, ud = tdesc(mask), tdesc(unet_in)
+    check(_lib.lib().vfx_unet_input_f32(_ptr(mel), C.byref(md), C.byref(ud), unet_in.shape[1], mel.shape[0], T, Tp,
+                                        _stream()), "vfx_unet_input_f32")
 
 
 def unet_output(unet_out, unet_in, mel, mask, logmel, denoised, T, Tp):
     _need_cuda(unet_out, unet_in, mel, mask, logmel, denoised)
-    md = tdesc(mask)
-    check(_lib.lib().vfx_unet_output_f32(_ptr(unet_out), _ptr(unet_in), _ptr(mel), C.byref(md), _ptr(logmel),
+    md, od, ud = tdesc(mask), tdesc(unet_out), tdesc(unet_in)
+    check(_lib.lib().vfx_unet_output_f32(C.byref(od), C.byref(ud), _ptr(mel), C.byref(md), _ptr(logmel),
                                          _ptr(denoised), mel.shape[0], T, Tp, _stream()), "vfx_unet_output_f32")
 
 
