@@ -120,10 +120,19 @@ def main():
     dom = max(by_tile.items(), key=lambda kv: kv[1][2])
     tile, (launches, macs, secs) = dom
     achieved = 2.0 * macs / secs / 1e12
+    # HBM bytes per launch of that kernel: PMC counters cannot be read live; they come from the committed
+    # rocprofv3 --pmc passes over this same command (profiles/r01_pmc_hbm_traffic_bench_b32.json)
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bench_b32.json")
+    if os.path.exists(tfile) and args.batch == 32 and abs(args.seconds - 10.0) < 1e-9:
+        want = "conv_taps_kernel<%d, %d," % (tile // 100000, tile // 100 % 1000)
+        for kname, rec in json.load(open(tfile))["kernels"].items():
+            if want in kname and ", %d, true>" % (tile % 100) in kname:
+                traffic = rec["hbm_bytes_per_launch"]
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-        "kernel": "conv_taps_kernel<BM=%d,BL=%d,KC=%d>" % (tile // 100000, tile // 100 % 1000, tile % 100),
+        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+        "kernel": "conv_taps_kernel<BM=%d,BL=%d,KC=%d,FAST>" % (tile // 100000, tile // 100 % 1000, tile % 100),
         "launches_per_step": launches // args.steps,
         "avg_launch_ms": round(secs / launches * 1e3, 4),
         "algorithmic_gflop_per_launch": round(2.0 * macs / launches / 1e9, 3),
