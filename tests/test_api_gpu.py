@@ -62,6 +62,21 @@ def test_segmentation_31s_matches_oracle(vf):
     assert _rms(out, ref) < 2e-5
 
 
+def test_long_input_segments_batched_equals_sequential(vf):
+    """61 s input = two full 30 s segments + a 1 s tail.  Restoring the full segments as one batch
+    must equal restoring them one by one (the reference's order), hard cuts at the same samples."""
+    n = 61 * 44100
+    g = torch.Generator().manual_seed(4)
+    wav = (0.1 * torch.randn(n, generator=g)).numpy()
+    vf.segment_batch = 8
+    a = vf.restore_inmem(wav, cuda=True)
+    vf.segment_batch = 1
+    b = vf.restore_inmem(wav, cuda=True)
+    vf.segment_batch = 8
+    assert a.shape == b.shape == (1, n)
+    assert _rms(a, b) < 2e-5
+
+
 def test_vocoder_forward_and_plugin_hook(vf, seeded_states):
     voc = voicefixer_amd.Vocoder.from_state(seeded_states[0])
     g = np.load(os.path.join(GOLDEN, "vocoder_B2_T24.npz"))
