@@ -144,7 +144,7 @@ __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const C
     for (int j = 0; j < MAXWV; ++j) st.wv[j] = *reinterpret_cast<const float4*>(wc + st.w_off[j]);
 }
 
-template <bool FAST, int MAXXV, int MAXWV>
+template <bool FAST, int NTHR, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, int c0, float* xs,
                                             float* ws, const float* aff, int nxv, int nwv, int xtotal,
                                             int wtotal, int tid, int lshift, bool range_mask) {
@@ -189,7 +189,7 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                 for (int k = 0; k < 4; ++k)
                     if (((l + k) & in_mask) == in_mask) e[k] = 0.f;
             }
-            int i = tid + 256 * j;
+            int i = tid + NTHR * j;
             i = i < xtotal ? i : xtotal - 1;  // duplicates rewrite the tile's last vector with the same value
             *reinterpret_cast<float4*>(xs + 4 * i) = make_float4(e[0], e[1], e[2], e[3]);
         }
@@ -197,7 +197,7 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
 #pragma unroll
     for (int j = 0; j < MAXWV; ++j)
         if (j < nwv) {
-            int i = tid + 256 * j;
+            int i = tid + NTHR * j;
             i = i < wtotal ? i : wtotal - 1;
             *reinterpret_cast<float4*>(ws + 4 * i) = st.wv[j];
         }
@@ -290,10 +290,11 @@ __device__ __forceinline__ int fast_div(int i, int d, float inv) {
 }
 
 template <int BM, int BL, int WGM, int WGL, int KC, bool FAST>
-__global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kernel(const ConvArgs a) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
+    constexpr int NTHR = 64 * WGM * WGL;
     constexpr int MAXXV = StageCfg<KC>::MAXXV, MAXWV = StageCfg<KC>::MAXWV;
-    static_assert(WGM * WGL == 4 && RM >= 1 && RL >= 1, "4 waves per workgroup");
+    static_assert((WGM * WGL == 4 || WGM * WGL == 8) && RM >= 1 && RL >= 1, "4 or 8 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -319,8 +320,8 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     const int sv = segw >> 2;                 // float4 per LDS row
     const int xtotal = nseg * KC * sv;        // float4 in the activation tile
     const int wtotal = nt * KC * (BM / 4);    // float4 in the weight tile
-    const int nxv = (xtotal + 255) >> 8;      // staging slots in use (uniform)
-    const int nwv = (wtotal + 255) >> 8;
+    const int nxv = (xtotal + NTHR - 1) / NTHR;  // staging slots in use (uniform)
+    const int nwv = (wtotal + NTHR - 1) / NTHR;
 
     const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
     const int xcs = (int)a.x_cs;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     const float inv_sv = 1.0f / (float)sv, inv_row = 1.0f / (float)(KC * sv);
 #pragma unroll
     for (int j = 0; j < MAXXV; ++j) {
-        int i = tid + 256 * j;
+        int i = tid + NTHR * j;
         i = i < xtotal ? i : xtotal - 1;
         const int s = fast_div(i, KC * sv, inv_row);
         const int rem = i - s * (KC * sv);
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < MAXWV; ++j) {
-        int i = tid + 256 * j;
+        int i = tid + NTHR * j;
         i = i < wtotal ? i : wtotal - 1;
         const int t = i / (KC * (BM / 4));
         const int rem = i - t * (KC * (BM / 4));
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
     // per-channel (scale, shift) of the fused BatchNorm pre-activation: one LDS copy per workgroup
     float* aff = smem + 2 * bufstride;
     if (a.pre_act == VFX_PRE_AFFINE_LRELU) {
-        for (int c = tid; c < a.CinPad; c += 256) {
+        for (int c = tid; c < a.CinPad; c += NTHR) {
             aff[2 * c] = c < a.Cin ? a.pre_scale[c] : 1.f;
             aff[2 * c + 1] = c < a.Cin ? a.pre_shift[c] : 0.f;
         }
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
             range_mask |= (o < 0) || (o + segw > a.Lin);
         }
     }
-    stage_write<FAST>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
+    stage_write<FAST, NTHR>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
     if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0);
     __syncthreads();
 #if VFX_ABL & 8
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void conv_taps_kernel(const ConvArgs a) {
 #if !(VFX_ABL & 1)
         if (s + 1 < S) {
             float* nxs = smem + ((s + 1) & 1) * bufstride;
-            stage_write<FAST>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL,
+            stage_write<FAST, NTHR>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL,
                               range_mask);
 #if VFX_ABL & 8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -530,7 +531,7 @@ static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGL), lds, s, a);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -657,6 +658,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
 
     // K-chunk depth: 8 channels per chunk unless the staged tiles would need more than 4 float4 per
     // thread (activations) / the weight tile more than its slot budget -> 4 channels per chunk
+    // development switch: VFX_WAVES8=1 runs the two big tiles with 8 waves (wave tile 32x64)
+    static const bool waves8_env = getenv("VFX_WAVES8") && atoi(getenv("VFX_WAVES8")) != 0;
+    const bool waves8 = waves8_env && ((tc.BM == 128 && tc.BL == 128) || (tc.BM == 64 && tc.BL == 256));
+    const int nthr = waves8 ? 512 : 256;
     ConvTables tb;
     int KC = 8;
     for (;;) {
@@ -665,8 +670,8 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         if (rc) return rc;
         int maxseg = 0;
         for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
-        const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * 256;
-        const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 8 ? 4 : 5) * 1024;
+        const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * nthr;
+        const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 8 ? 4 : 5) * 4 * nthr;
         if (xfit && wfit) break;
         if (KC == 4) return VFX_ERANGE;
         KC = 4;
@@ -714,6 +719,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     if (tc.BM == BM_ && tc.BL == BL_)                                                     \
         return KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, ntiles, gy, B, lds, stream) \
                        : launch_cfg<BM_, BL_, WGM_, WGL_, 4>(a, ntiles, gy, B, lds, stream);
+    if (waves8) {
+        VFX_CASE(128, 128, 4, 2)
+        VFX_CASE(64, 256, 2, 4)
+    }
     VFX_CASE(128, 128, 2, 2)
     VFX_CASE(64, 256, 1, 4)
     VFX_CASE(128, 64, 4, 1)
