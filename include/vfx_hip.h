@@ -25,6 +25,7 @@
 #ifndef VFX_HIP_H
 #define VFX_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -144,6 +145,17 @@ int vfx_frontend_init(const float* window, const float* twiddle, const int32_t* 
  * Replaces voicefixer/base.py:78-85 (_pre): fDomainHelper.py:81-110 + mel_scale.py:63-77. */
 int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int N, float* mel,
                      vfx_stream_t stream);
+
+/* mode-1 pre-filter, VoiceFixer.remove_higher_frequency (voicefixer/base.py:87-104): STFT 2048/512
+ * (periodic hann, centred, zero padding) -> per-bin clipped log10 energy -> cut-off bin at `ratio`
+ * of the cumulative energy -> bins >= cut-off zeroed -> ISTFT (overlap-add, window-sum-square
+ * normalisation).  wav [B][N] -> out [B][512*(N/512)].  workspace: vfx_hf_workspace_bytes(B, N)
+ * device bytes, 16-byte aligned.  cutoff_out (device, B int32, may be NULL) receives the cut-off
+ * bin index of every utterance.  Needs vfx_frontend_init (window, twiddles). */
+size_t vfx_hf_workspace_bytes(int B, int N);
+int vfx_hf_cut_f32(const float* wav, int64_t wav_stride, int B, int N, float* out, int64_t out_stride,
+                   float ratio, void* workspace, size_t workspace_bytes, int32_t* cutoff_out,
+                   vfx_stream_t stream);
 
 /* (B,T,128) frame-major <-> channel-major (B,128,ld) transposes used around the denoiser. */
 int vfx_tm_to_cm_f32(const float* src, float* dst, int B, int T, int C, int64_t dst_bstride,

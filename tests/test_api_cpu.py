@@ -52,9 +52,8 @@ def test_no_cpu_fallback(seeded_states):
 
 def test_modes(seeded_states):
     vf = voicefixer_amd.VoiceFixer.from_state(*seeded_states)
-    for mode in (1, 2):
-        with pytest.raises(NotImplementedError):
-            vf.restore_inmem(np.zeros(4410, np.float32), mode=mode)
+    with pytest.raises(NotImplementedError):
+        vf.restore_inmem(np.zeros(4410, np.float32), mode=2)
     with pytest.raises(ValueError):
         vf.restore_inmem(np.zeros(4410, np.float32), mode=7)
 
@@ -122,3 +121,16 @@ def test_oracle_frontend_length_identity():
     c = oracle_frontend.wav_to_cond(torch.randn(96076, generator=g).numpy() * 0.1)
     assert tuple(c.shape) == (1, 128, 222) and 441 * c.shape[-1] == 97902
     assert c.min() >= -4.0 and c.max() <= 4.0 and (c[..., -4:] == -4.0).all()
+
+
+def test_oracle_mode1_prefilter_length_identity():
+    """132 300 samples -> 132 096 (= the reference's output_mode_1.flac length)."""
+    from oracle import oracle
+    g = torch.Generator().manual_seed(1)
+    t = np.arange(132300) / 44100.0
+    wav = (0.05 * torch.randn(132300, generator=g).numpy() + 0.3 * np.sin(2 * np.pi * 300 * t)).astype(np.float32)
+    y, cut = oracle.remove_higher_frequency(wav)
+    assert y.shape == (132096,) and 0 < cut <= 1024
+    # bins above the cut-off carry (almost) no energy afterwards
+    spec = np.abs(np.fft.rfft(y[4096:4096 + 2048] * np.hanning(2048)))
+    assert spec[min(cut + 8, 1024):].max() < 1e-3 * spec.max()

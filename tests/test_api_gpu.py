@@ -121,3 +121,15 @@ def test_vocoder_oracle_file(seeded_states, tmp_path):
         ref = oracle.vocoder_generator(oracle_frontend.wav_to_cond(audio_io.load_wav(fin)), seeded_states[0])
     want = oracle.to_int16((ref[0] * 2 ** 15).numpy())[0].astype(np.float32) / 32768.0
     assert np.abs(out - want).max() <= 1.5 / 32768.0
+
+
+def test_mode1_matches_oracle(vf):
+    """mode 1 = high-frequency cut (device) + the mode-0 path on the shortened segment."""
+    g = np.load(os.path.join(GOLDEN, "restore_speech_T51.npz"))
+    wav = g["wav"]
+    out = vf.restore_inmem(wav, cuda=True, mode=1)
+    filt, _ = oracle.remove_higher_frequency(wav)
+    with torch.no_grad():
+        ref = oracle.restore_inmem(filt, *_states(vf))
+    assert out.shape == ref.shape == (1, 512 * (len(wav) // 512))
+    assert _rms(out, ref) < 1e-4

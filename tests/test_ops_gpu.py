@@ -384,3 +384,21 @@ def test_bad_arguments_fail_loudly():
         ops.conv1d(x, w, None, torch.zeros((1, 48, 100), device=DEV), 100, 3)
     with pytest.raises(_lib.VfxError):
         ops.conv1d(torch.zeros((1, 64, 100)), w, None, x, 100, 3)  # CPU tensor
+
+
+@pytest.mark.parametrize("n", [22050, 132300])
+def test_hf_cut_mode1_prefilter(n):
+    """vfx_hf_cut_f32 vs the numpy restatement of remove_higher_frequency (librosa semantics)."""
+    g = torch.Generator().manual_seed(50)
+    t = np.arange(n) / 44100.0
+    w0 = (0.03 * torch.randn(n, generator=g).numpy() + 0.3 * np.sin(2 * np.pi * 440 * t)).astype(np.float32)
+    w1 = (0.2 * torch.randn(n, generator=g).numpy()).astype(np.float32)
+    wav = torch.from_numpy(np.stack([w0, w1])).to(DEV)
+    out, cut = ops.hf_cut(wav, n, 0.95)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (2, 512 * (n // 512))
+    for b, w in enumerate((w0, w1)):
+        ref, rcut = oracle.remove_higher_frequency(w)
+        assert abs(int(cut[b]) - rcut) <= 1  # float32 summation order may move the threshold crossing by one bin
+        if int(cut[b]) == rcut:
+            assert np.abs(out[b].cpu().numpy() - ref).max() < 2e-5

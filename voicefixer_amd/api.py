@@ -13,9 +13,9 @@ in libvfx_hip on the MI355X; there is NO CPU implementation behind this API:
   * ``cuda=False`` -> same kernels, results copied back to host tensors (the reference would
     compute on the CPU; numerically equivalent within the parity tolerance).  Without a visible
     device either setting raises -- nothing silently falls back.
-  * ``mode=0`` only.  ``mode=1`` (librosa pre-filter, base.py:87-104) and ``mode=2`` (train-mode
-    BatchNorm/Dropout, exempt from the reference's own check, test/test.py:58) raise
-    NotImplementedError: they are rows of SURVEY.md 8(f), not of the hot path.
+  * ``mode=0`` and ``mode=1`` (``remove_higher_frequency`` pre-filter, base.py:87-104, run on the
+    device by ``vfx_hf_cut_f32``).  ``mode=2`` (train-mode BatchNorm/Dropout, nondeterministic and
+    exempt from the reference's own check, test/test.py:58) raises NotImplementedError.
 """
 import os
 
@@ -155,12 +155,12 @@ class VoiceFixer(nn.Module):
 
     @staticmethod
     def _check_mode(mode):
-        if mode == 0:
+        if mode in (0, 1):
             return
-        if mode in (1, 2):
+        if mode == 2:
             raise NotImplementedError(
-                "mode=%d is outside the MI355X hot path (mode 1: librosa pre-filter, mode 2: train-mode "
-                "BatchNorm/Dropout); only mode 0 is implemented" % mode)
+                "mode=2 (train-mode BatchNorm + Dropout) is nondeterministic in the reference and outside "
+                "the MI355X path; modes 0 and 1 are implemented")
         raise ValueError("mode must be 0, 1 or 2")
 
     @torch.no_grad()
@@ -187,13 +187,23 @@ class VoiceFixer(nn.Module):
         for i in range(0, len(full), self.segment_batch):
             grp = full[i:i + self.segment_batch]
             seg = torch.from_numpy(np.stack([wav[a:b] for a, b in grp])).to(pipe.device)
-            out = pipe.restore(seg, SEG_LENGTH, your_vocoder_func)
+            out = self._restore_segments(pipe, seg, SEG_LENGTH, mode, your_vocoder_func)
             res.extend(out[k:k + 1] for k in range(len(grp)))
         for a, b in tail:
             seg = torch.from_numpy(np.ascontiguousarray(wav[a:b]))[None].to(pipe.device)
-            res.append(pipe.restore(seg, b - a, your_vocoder_func))
+            res.append(self._restore_segments(pipe, seg, b - a, mode, your_vocoder_func))
         out = torch.cat(res, -1)
         return out.cpu().numpy()
+
+    @staticmethod
+    def _restore_segments(pipe, seg, n, mode, your_vocoder_func):
+        """One batch of equal-length segments through the path; mode 1 first shortens every segment to
+        512*(n//512) samples by the device-side high-frequency cut (base.py:121-122)."""
+        if mode == 1:
+            from . import ops
+            seg, _ = ops.hf_cut(seg, n, 0.95)
+            n = seg.shape[1]
+        return pipe.restore(seg, n, your_vocoder_func)
 
     @torch.no_grad()
     def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32):

@@ -122,3 +122,181 @@ extern "C" int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int
     VFX_LAUNCHED();
     return vfx_last_error();
 }
+
+
+// ======================================================================================
+// mode-1 pre-filter: VoiceFixer.remove_higher_frequency (voicefixer/base.py:87-104)
+//   S = librosa.stft(wav)            n_fft 2048, hop 512, periodic hann, centre, zero ("constant") padding
+//   E[f] = sum_t max(0, log10(|S[f,t]| + 1e-8)) ; cut = first i with sum_{f<=i} E[f] >= 0.95 * sum E
+//   S'[f,t] = (f < cut) ? |S| * (S / (|S| + 1e-8)) : 0 ; y = librosa.istft(S')   (length 512 * (N // 512))
+// Five small kernels; everything stays on the device (the reference does this in numpy on the host).
+// ======================================================================================
+#define HF_HOP 512
+
+__device__ __forceinline__ float2* fft2048_lds(float2* buf0, float2* buf1, const float2* tw, int tid) {
+    float2* src = buf0;
+    float2* dst = buf1;
+#pragma unroll 1
+    for (int ns_log = 0; ns_log < 11; ++ns_log) {
+        const int Ns = 1 << ns_log;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int j = tid + 256 * k;
+            const int kk = j & (Ns - 1);
+            const float2 w = tw[kk << (10 - ns_log)];
+            const float2 u = src[j];
+            const float2 v0 = src[j + NFFT / 2];
+            const float2 v = make_float2(v0.x * w.x - v0.y * w.y, v0.x * w.y + v0.y * w.x);
+            const int j0 = ((j - kk) << 1) + kk;
+            dst[j0] = make_float2(u.x + v.x, u.y + v.y);
+            dst[j0 + Ns] = make_float2(u.x - v.x, u.y - v.y);
+        }
+        __syncthreads();
+        float2* tmp = src; src = dst; dst = tmp;
+    }
+    return src;
+}
+
+// (b, frame) -> complex spectrum S[b][t][0..1024]
+__global__ __launch_bounds__(256) void hf_stft_kernel(const float* __restrict__ wav, long long wav_stride, int N, int T,
+                                                      float2* __restrict__ S, const float* __restrict__ window,
+                                                      const float2* __restrict__ twiddle) {
+    __shared__ float2 buf0[NFFT];
+    __shared__ float2 buf1[NFFT];
+    __shared__ float2 tw[NFFT / 2];
+    const int tid = threadIdx.x, t = blockIdx.x, b = blockIdx.y;
+    const float* x = wav + (long long)b * wav_stride;
+    for (int i = tid; i < NFFT / 2; i += 256) tw[i] = twiddle[i];
+    const int base = HF_HOP * t - NFFT / 2;
+#pragma unroll
+    for (int k = 0; k < NFFT / 256; ++k) {
+        const int n = tid + 256 * k;
+        const int g = base + n;
+        buf0[n] = make_float2((g >= 0 && g < N) ? x[g] * window[n] : 0.f, 0.f);
+    }
+    __syncthreads();
+    const float2* r = fft2048_lds(buf0, buf1, tw, tid);
+    float2* out = S + ((long long)b * T + t) * (NFFT / 2 + 1);
+    for (int i = tid; i <= NFFT / 2; i += 256) out[i] = r[i];
+}
+
+// per bin: E[b][f] = sum_t max(0, log10(|S| + 1e-8)), fixed summation order (deterministic cut-off)
+__global__ __launch_bounds__(256) void hf_energy_kernel(const float2* __restrict__ S, int T, float* __restrict__ E) {
+    const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (f > NFFT / 2) return;
+    const float2* p = S + (long long)b * T * (NFFT / 2 + 1) + f;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float2 c = p[(long long)t * (NFFT / 2 + 1)];
+        acc += fmaxf(log10f(sqrtf(c.x * c.x + c.y * c.y) + 1e-8f), 0.f);
+    }
+    E[b * (NFFT / 2 + 1) + f] = acc;
+}
+
+// the reference's while loop (base.py:97-101), one thread per utterance
+__global__ void hf_cutoff_kernel(const float* __restrict__ E, float ratio, int* __restrict__ cut) {
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float* e = E + b * (NFFT / 2 + 1);
+    float total = 0.f;
+    for (int f = 0; f <= NFFT / 2; ++f) total += e[f];
+    const float threshold = total * ratio;
+    float level = e[0];
+    int i = 0;
+    while (i < NFFT / 2 && level < threshold) {  // the reference would index past the end at i = 1024
+        level += e[i + 1];
+        ++i;
+    }
+    cut[b] = i;
+}
+
+// (b, frame): masked spectrum -> inverse real FFT -> windowed frame F[b][t][2048]
+__global__ __launch_bounds__(256) void hf_iframe_kernel(const float2* __restrict__ S, int T, const int* __restrict__ cut,
+                                                        float* __restrict__ F, const float* __restrict__ window,
+                                                        const float2* __restrict__ twiddle) {
+    __shared__ float2 buf0[NFFT];
+    __shared__ float2 buf1[NFFT];
+    __shared__ float2 tw[NFFT / 2];
+    const int tid = threadIdx.x, t = blockIdx.x, b = blockIdx.y;
+    for (int i = tid; i < NFFT / 2; i += 256) tw[i] = twiddle[i];
+    const int c0 = cut[b];
+    const float2* sp = S + ((long long)b * T + t) * (NFFT / 2 + 1);
+    // Hermitian extension of the masked spectrum, conjugated: IFFT(X) = conj(FFT(conj(X))) / N
+#pragma unroll
+    for (int k = 0; k < NFFT / 256; ++k) {
+        const int n = tid + 256 * k;
+        const int f = n <= NFFT / 2 ? n : NFFT - n;
+        float2 c = make_float2(0.f, 0.f);
+        if (f < c0) {
+            const float2 v = sp[f];
+            const float m = sqrtf(v.x * v.x + v.y * v.y);
+            const float g = m / (m + 1e-8f);  // spec * cos + j spec * sin with cos = re / (mag + EPS)
+            c = make_float2(v.x * g, v.y * g);
+        }
+        // irfft ignores the imaginary part of the DC and Nyquist bins
+        if (f == 0 || f == NFFT / 2) c.y = 0.f;
+        buf0[n] = make_float2(c.x, n <= NFFT / 2 ? -c.y : c.y);
+    }
+    __syncthreads();
+    const float2* r = fft2048_lds(buf0, buf1, tw, tid);
+    float* out = F + ((long long)b * T + t) * NFFT;
+    for (int i = tid; i < NFFT; i += 256) out[i] = r[i].x * (1.0f / NFFT) * window[i];
+}
+
+// overlap-add of 4 frames per sample + window-sum-square normalisation + centre trim
+__global__ __launch_bounds__(256) void hf_ola_kernel(const float* __restrict__ F, int T, const float* __restrict__ window,
+                                                     float* __restrict__ out, long long out_stride, int Nout) {
+    const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (i >= Nout) return;
+    const int n = i + NFFT / 2;  // position in the untrimmed signal
+    const int thi = n / HF_HOP < T - 1 ? n / HF_HOP : T - 1;
+    int tlo = (n - NFFT + HF_HOP) / HF_HOP;
+    if (n - NFFT + 1 <= 0) tlo = 0;
+    float acc = 0.f, wss = 0.f;
+    for (int t = tlo; t <= thi; ++t) {
+        const int k = n - t * HF_HOP;
+        if (k < 0 || k >= NFFT) continue;
+        acc += F[((long long)b * T + t) * NFFT + k];
+        wss += window[k] * window[k];
+    }
+    out[(long long)b * out_stride + i] = wss > 1.1754944e-38f ? acc / wss : acc;
+}
+
+extern "C" size_t vfx_hf_workspace_bytes(int B, int N) {
+    const size_t T = 1 + (size_t)N / HF_HOP;
+    return (size_t)B * T * (NFFT / 2 + 1) * sizeof(float2) + (size_t)B * T * NFFT * sizeof(float) +
+           (size_t)B * (NFFT / 2 + 1) * sizeof(float) + (size_t)B * sizeof(int) + 256;
+}
+
+extern "C" int vfx_hf_cut_f32(const float* wav, int64_t wav_stride, int B, int N, float* out, int64_t out_stride,
+                              float ratio, void* workspace, size_t workspace_bytes, int32_t* cutoff_out,
+                              vfx_stream_t stream) {
+    if (!wav || !out || !workspace || B <= 0 || N < HF_HOP || B > 65535) return VFX_EINVAL;
+    if (!d_window) return VFX_EINVAL;  // vfx_frontend_init not called
+    if (workspace_bytes < vfx_hf_workspace_bytes(B, N)) return VFX_ERANGE;
+    if (!vfx_aligned16(workspace)) return VFX_EALIGN;
+    const int T = 1 + N / HF_HOP;
+    const int Nout = HF_HOP * (N / HF_HOP);
+    char* ws = (char*)workspace;
+    float2* S = (float2*)ws;
+    ws += (size_t)B * T * (NFFT / 2 + 1) * sizeof(float2);
+    float* F = (float*)ws;
+    ws += (size_t)B * T * NFFT * sizeof(float);
+    float* E = (float*)ws;
+    ws += (size_t)B * (NFFT / 2 + 1) * sizeof(float);
+    int* cut = cutoff_out ? cutoff_out : (int*)ws;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(hf_stft_kernel, dim3(T, B), dim3(256), 0, s, wav, (long long)wav_stride, N, T, S, d_window,
+                       d_twiddle);
+    VFX_LAUNCHED();
+    hipLaunchKernelGGL(hf_energy_kernel, dim3((NFFT / 2 + 256) / 256, B), dim3(256), 0, s, S, T, E);
+    VFX_LAUNCHED();
+    hipLaunchKernelGGL(hf_cutoff_kernel, dim3(B), dim3(64), 0, s, E, ratio, cut);
+    VFX_LAUNCHED();
+    hipLaunchKernelGGL(hf_iframe_kernel, dim3(T, B), dim3(256), 0, s, S, T, cut, F, d_window, d_twiddle);
+    VFX_LAUNCHED();
+    hipLaunchKernelGGL(hf_ola_kernel, dim3((Nout + 255) / 256, B), dim3(256), 0, s, F, T, d_window, out,
+                       (long long)out_stride, Nout);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}

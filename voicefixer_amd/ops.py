@@ -190,6 +190,20 @@ def stft_mel(wav, mel, N):
           "vfx_stft_mel_f32")
 
 
+def hf_cut(wav, N, ratio=0.95):
+    """mode-1 pre-filter (remove_higher_frequency): wav (B, >=N) device -> ((B, 512*(N//512)), cut-off bins)."""
+    _need_cuda(wav)
+    frontend_init()
+    B = wav.shape[0]
+    nbytes = _lib.lib().vfx_hf_workspace_bytes(B, N)
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=wav.device)
+    out = torch.empty((B, 512 * (N // 512)), device=wav.device)
+    cut = torch.empty((B,), dtype=torch.int32, device=wav.device)
+    check(_lib.lib().vfx_hf_cut_f32(_ptr(wav), wav.stride(0), B, N, _ptr(out), out.stride(0), float(ratio), _ptr(ws),
+                                    nbytes, _ptr(cut), _stream()), "vfx_hf_cut_f32")
+    return out, cut
+
+
 def tm_to_cm(src, dst, T, Cn):
     """src (B,T,C) contiguous -> dst (B,C,>=T) view."""
     _need_cuda(src, dst)
