@@ -1,1 +1,1 @@
-python -m pytest tests -x -q -m gpu -k "hf_cut or mode1" 2>&1 | tail -8
+python -m pytest tests -x -q -m gpu 2>&1 | tail -4

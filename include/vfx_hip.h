@@ -146,6 +146,17 @@ int vfx_frontend_init(const float* window, const float* twiddle, const int32_t* 
 int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int N, float* mel,
                      vfx_stream_t stream);
 
+/* Vocoder.oracle front-end on the device (voicefixer/vocoder/base.py:61-71): peak[b] = max|wav[b]|
+ * (vfx_peak_f32, float bits in a uint32), then |librosa.stft(wav/peak)| (n_fft 2048, hop 441, zero
+ * "constant" padding, no clamp) and the slaney-normalised HTK filterbank of librosa.filters.mel,
+ * uploaded once in banded form by vfx_frontend_init_oracle -> mel [B][T][128].  Follow with
+ * vfx_mel_to_cond_ex_f32(apply_weight = 0). */
+int vfx_frontend_init_oracle(const int32_t* lo, const int32_t* hi, const int32_t* off, const float* coef,
+                             int nnz);
+int vfx_peak_f32(const float* y, int64_t y_bstride, int Ly, int B, uint32_t* peak, vfx_stream_t stream);
+int vfx_stft_mel_oracle_f32(const float* wav, int64_t wav_stride, int B, int N, const uint32_t* peak,
+                            float* mel, vfx_stream_t stream);
+
 /* mode-1 pre-filter, VoiceFixer.remove_higher_frequency (voicefixer/base.py:87-104): STFT 2048/512
  * (periodic hann, centred, zero padding) -> per-bin clipped log10 energy -> cut-off bin at `ratio`
  * of the cumulative energy -> bins >= cut-off zeroed -> ISTFT (overlap-add, window-sum-square
@@ -195,6 +206,10 @@ int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const float* bhh
  * model/util.py:8-36,69-80 + config.py:310-316. */
 int vfx_mel_to_cond_f32(const float* mel, const vfx_tensor* cond, int B, int T,
                         vfx_stream_t stream);
+/* same with the division by the analytic mel weights optional (0 for the Vocoder.oracle path,
+ * whose mel is already slaney-normalised: vocoder/base.py:72 has no weight division) */
+int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int T, int apply_weight,
+                           vfx_stream_t stream);
 
 /* Per-utterance peak rule + centre trim (voicefixer/base.py:131-135, _trim_center :63-76):
  * peak[b] = max|y[b,:]|; out[b, 0:N] = y[b, d/2 : d/2+N] * (peak>1 ? 1/peak : 1), d = Ly-N.

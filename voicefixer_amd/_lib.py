@@ -49,6 +49,10 @@ SIGNATURES = {
     "vfx_avgpool2x2_f32": (_I, [_T, _T, _I, _I, _I, _I, _P]),
     "vfx_frontend_init": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "vfx_stft_mel_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
+    "vfx_frontend_init_oracle": (_I, [_P, _P, _P, _P, _I]),
+    "vfx_peak_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
+    "vfx_stft_mel_oracle_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P, _P]),
+    "vfx_mel_to_cond_ex_f32": (_I, [_P, _T, _I, _I, _I, _P]),
     "vfx_hf_workspace_bytes": (C.c_size_t, [_I, _I]),
     "vfx_hf_cut_f32": (_I, [_P, C.c_int64, _I, _I, _P, C.c_int64, C.c_float, _P, C.c_size_t, _P, _P]),
     "vfx_tm_to_cm_f32": (_I, [_P, _P, _I, _I, _I, C.c_int64, C.c_int64, _P]),

@@ -98,17 +98,18 @@ class Vocoder(nn.Module):
     __call__ = forward  # usable directly as ``your_vocoder_func`` (with the default cuda=False)
 
     def oracle(self, fpath, out_path, cuda=False):
-        """wav file -> ground-truth mel (librosa-style STFT + slaney HTK mel, on the host) ->
-        vocoder -> wav file (voicefixer/vocoder/base.py:58-77)."""
-        from . import oracle_frontend
+        """wav file -> ground-truth mel (librosa-style STFT + slaney HTK mel) -> vocoder -> wav file
+        (voicefixer/vocoder/base.py:58-77); only the file decode/encode runs on the host."""
+        from . import ops
         wav = audio_io.load_wav(fpath, self.rate, mono=True)
-        cond = oracle_frontend.wav_to_cond(wav)  # (1, 128, T') float32, normalised + padded
         eng = self._get_engine()
-        c = cond.to(eng.device)
-        Tc = c.shape[-1]
-        buf = torch.empty((1, 128, (Tc + 3) // 4 * 4), device=eng.device)
-        buf[:, :, :Tc] = c
-        wav_re, L = eng.forward_cond(buf, Tc)
+        w = torch.from_numpy(wav)[None].to(eng.device)
+        N = w.shape[1]
+        mel, T = ops.oracle_mel(w, N)            # wav/max|wav| -> |STFT| -> slaney mel, on the device
+        Tc = T + T % 2 + 4
+        cond = ops.guarded(1, 128, Tc, engine.G_TILE, eng.device)
+        ops.mel_to_cond_plain(mel, cond, T)      # amp_to_db - 20, normalize, pre()
+        wav_re, L = eng.forward_cond(cond, Tc)
         audio_io.save_wave((wav_re[:, 0, :L] * 2 ** 15).cpu().numpy(), out_path, sample_rate=self.rate)
 
 

@@ -228,7 +228,8 @@ extern "C" int vfx_unet_output_f32(const vfx_tensor* unet_out, const vfx_tensor*
 // vocoder front-end: mel (B,T,128) -> cond (B,128,T') channel-major
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mel_to_cond_kernel(const float* __restrict__ mel, float* __restrict__ cond,
-                                                          long long c_bs, long long c_cs, int T, int Tc) {
+                                                          long long c_bs, long long c_cs, int T, int Tc,
+                                                          int apply_weight) {
     __shared__ float tile[32][129];
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
     const int tid = threadIdx.x;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(256) void mel_to_cond_kernel(const float* __restric
         const int c = tid & 127;
         // w_k = a*exp(b*k), k = 1..128 in float32 (config.py:296-316: torch.linspace then exp)
         const float kf = (float)(c + 1);
-        const float wgt = 18.8927416350036f * expf(0.0269863588184314f * kf);
+        const float wgt = apply_weight ? 18.8927416350036f * expf(0.0269863588184314f * kf) : 1.0f;
         for (int r = tid >> 7; r < 32; r += 2) {
             const int t = t0 + r;
             float v = -4.0f;
@@ -256,13 +257,20 @@ __global__ __launch_bounds__(256) void mel_to_cond_kernel(const float* __restric
     }
 }
 
+extern "C" int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int T, int apply_weight,
+                                      vfx_stream_t stream);
 extern "C" int vfx_mel_to_cond_f32(const float* mel, const vfx_tensor* cond, int B, int T, vfx_stream_t stream) {
+    return vfx_mel_to_cond_ex_f32(mel, cond, B, T, 1, stream);
+}
+
+extern "C" int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int T, int apply_weight,
+                                      vfx_stream_t stream) {
     if (!mel || !cond || !cond->ptr || B <= 0 || T <= 0 || B > 65535) return VFX_EINVAL;
     if (cond->lstride != 1) return VFX_EALIGN;
     const int Tc = T + (T & 1) + 4;
     dim3 grid((Tc + 31) / 32, B);
     hipLaunchKernelGGL(mel_to_cond_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel, (float*)cond->ptr,
-                       cond->bstride, cond->cstride, T, Tc);
+                       cond->bstride, cond->cstride, T, Tc, apply_weight);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -297,6 +305,18 @@ __global__ __launch_bounds__(256) void trim_kernel(const float* __restrict__ y, 
     float v = y[(long long)b * y_bs + start + i];
     if (pk > 1.0f) v = v / pk;
     out[(long long)b * o_bs + i] = v;
+}
+
+extern "C" int vfx_peak_f32(const float* y, int64_t y_bstride, int Ly, int B, uint32_t* peak, vfx_stream_t stream) {
+    if (!y || !peak || B <= 0 || Ly <= 0 || B > 65535) return VFX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(peak, 0, sizeof(uint32_t) * B, s);
+    if (e != hipSuccess) return (int)e;
+    int nb = (Ly + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak);
+    VFX_LAUNCHED();
+    return vfx_last_error();
 }
 
 extern "C" int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride, int N, int B,

@@ -43,8 +43,10 @@ extern "C" int vfx_frontend_init(const float* window, const float* twiddle, cons
     return VFX_OK;
 }
 
+template <bool ORACLE>
 __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__ wav, long long wav_stride, int N,
                                                        int T, float* __restrict__ mel,
+                                                       const uint32_t* __restrict__ peak,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twiddle, const int* __restrict__ lo,
                                                        const int* __restrict__ hi, const int* __restrict__ off,
@@ -62,15 +64,23 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
     for (int f = 0; f < FPW; ++f) {
         const int t = blockIdx.x * FPW + f;
         if (t >= T) break;  // uniform
-        // ---- windowed frame, reflect index map: x_p[n] = x[reflect(HOP*t + n - 1024)]
+        // ---- windowed frame.  restore path: reflect index map x_p[n] = x[reflect(HOP*t + n - 1024)];
+        // Vocoder.oracle path (librosa >= 0.10 stft): zero padding and the wav / max|wav| pre-scale
         const int base = HOP * t - NFFT / 2;
+        const float gain = ORACLE ? 1.0f / __uint_as_float(peak[b]) : 1.0f;
 #pragma unroll
         for (int k = 0; k < NFFT / 256; ++k) {
             const int n = tid + 256 * k;
             int g = base + n;
-            if (g < 0) g = -g;
-            if (g >= N) g = 2 * (N - 1) - g;
-            buf0[n] = make_float2(x[g] * window[n], 0.f);
+            float v;
+            if (ORACLE) {
+                v = (g >= 0 && g < N) ? x[g] * gain : 0.f;
+            } else {
+                if (g < 0) g = -g;
+                if (g >= N) g = 2 * (N - 1) - g;
+                v = x[g];
+            }
+            buf0[n] = make_float2(v * window[n], 0.f);
         }
         __syncthreads();
         // ---- Stockham radix-2, 11 passes
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
         // ---- magnitudes of bins 0..1024: sqrt(clamp(re^2 + im^2, 1e-8))
         for (int i = tid; i <= NFFT / 2; i += 256) {
             const float2 c = src[i];
-            mag[i] = sqrtf(fmaxf(c.x * c.x + c.y * c.y, 1e-8f));
+            mag[i] = ORACLE ? sqrtf(c.x * c.x + c.y * c.y) : sqrtf(fmaxf(c.x * c.x + c.y * c.y, 1e-8f));
         }
         __syncthreads();
         // ---- banded mel
@@ -117,8 +127,44 @@ extern "C" int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int
     if (!d_window) return VFX_EINVAL;  // vfx_frontend_init not called
     const int T = 1 + N / HOP;
     dim3 grid((T + FPW - 1) / FPW, B);
-    hipLaunchKernelGGL(stft_mel_kernel, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N, T, mel,
-                       d_window, d_twiddle, d_lo, d_hi, d_off, d_coef);
+    hipLaunchKernelGGL(stft_mel_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N,
+                       T, mel, (const uint32_t*)nullptr, d_window, d_twiddle, d_lo, d_hi, d_off, d_coef);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}
+
+// ---- Vocoder.oracle front-end (voicefixer/vocoder/base.py:61-71): wav / max|wav| -> |librosa.stft|
+// (hop 441, zero padding) -> slaney-normalised HTK mel (librosa.filters.mel), tables uploaded once.
+static int* d_olo = nullptr;
+static int* d_ohi = nullptr;
+static int* d_ooff = nullptr;
+static float* d_ocoef = nullptr;
+
+extern "C" int vfx_frontend_init_oracle(const int32_t* lo, const int32_t* hi, const int32_t* off, const float* coef,
+                                        int nnz) {
+    if (!lo || !hi || !off || !coef || nnz <= 0) return VFX_EINVAL;
+    auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        hipError_t e = hipMalloc(dst, bytes);
+        if (e != hipSuccess) return e;
+        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    hipError_t e;
+    if ((e = up((void**)&d_olo, lo, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = up((void**)&d_ohi, hi, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = up((void**)&d_ooff, off, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = up((void**)&d_ocoef, coef, (size_t)nnz * sizeof(float))) != hipSuccess) return (int)e;
+    return VFX_OK;
+}
+
+extern "C" int vfx_stft_mel_oracle_f32(const float* wav, int64_t wav_stride, int B, int N, const uint32_t* peak,
+                                       float* mel, vfx_stream_t stream) {
+    if (!wav || !mel || !peak || B <= 0 || N < 1 || B > 65535) return VFX_EINVAL;
+    if (!d_window || !d_olo) return VFX_EINVAL;  // vfx_frontend_init / vfx_frontend_init_oracle not called
+    const int T = 1 + N / HOP;
+    dim3 grid((T + FPW - 1) / FPW, B);
+    hipLaunchKernelGGL(stft_mel_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N, T,
+                       mel, peak, d_window, d_twiddle, d_olo, d_ohi, d_ooff, d_ocoef);
     VFX_LAUNCHED();
     return vfx_last_error();
 }

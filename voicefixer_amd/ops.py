@@ -190,6 +190,39 @@ def stft_mel(wav, mel, N):
           "vfx_stft_mel_f32")
 
 
+_oracle_ready = False
+
+
+def oracle_mel(wav, N):
+    """Vocoder.oracle front-end on the device: wav (B, >=N) -> slaney mel (B, T, 128) of wav/max|wav|."""
+    global _oracle_ready
+    _need_cuda(wav)
+    frontend_init()
+    if not _oracle_ready:
+        from .frontend_tables import banded
+        from .oracle_frontend import mel_basis
+        lo, hi, off, coef = banded(torch.from_numpy(mel_basis().T.copy()))
+        check(_lib.lib().vfx_frontend_init_oracle(lo.ctypes.data, hi.ctypes.data, off.ctypes.data, coef.ctypes.data,
+                                                  int(coef.shape[0])), "vfx_frontend_init_oracle")
+        _oracle_ready = True
+    B = wav.shape[0]
+    T = 1 + N // 441
+    peak = torch.empty((B,), dtype=torch.int32, device=wav.device)
+    check(_lib.lib().vfx_peak_f32(_ptr(wav), wav.stride(0), N, B, _ptr(peak), _stream()), "vfx_peak_f32")
+    mel = torch.empty((B, T, 128), device=wav.device)
+    check(_lib.lib().vfx_stft_mel_oracle_f32(_ptr(wav), wav.stride(0), B, N, _ptr(peak), _ptr(mel), _stream()),
+          "vfx_stft_mel_oracle_f32")
+    return mel, T
+
+
+def mel_to_cond_plain(mel, cond, T):
+    """dB / normalise / clip / tail-pad WITHOUT the mel-weight division (Vocoder.oracle path)."""
+    _need_cuda(mel, cond)
+    cd = tdesc(cond)
+    check(_lib.lib().vfx_mel_to_cond_ex_f32(_ptr(mel), C.byref(cd), mel.shape[0], T, 0, _stream()),
+          "vfx_mel_to_cond_ex_f32")
+
+
 def hf_cut(wav, N, ratio=0.95):
     """mode-1 pre-filter (remove_higher_frequency): wav (B, >=N) device -> ((B, 512*(N//512)), cut-off bins)."""
     _need_cuda(wav)
