@@ -88,7 +88,7 @@ struct ConvArgs {
 template <int KC>
 struct StageCfg {
     static constexpr int MAXXV = 4;              // float4 per thread for the activation tile
-    static constexpr int MAXWV = KC == 8 ? 4 : 5;  // float4 per thread for the weight tile
+    static constexpr int MAXWV = KC == 16 ? 6 : (KC == 8 ? 4 : 5);  // float4 per thread for the weight tile
 };
 
 // Per-thread staging state: which float4 of the activation / weight tile this thread moves.
@@ -662,8 +662,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     static const bool waves8_env = getenv("VFX_WAVES8") && atoi(getenv("VFX_WAVES8")) != 0;
     const bool waves8 = waves8_env && ((tc.BM == 128 && tc.BL == 128) || (tc.BM == 64 && tc.BL == 256));
     const int nthr = waves8 ? 512 : 256;
+    // development switch: VFX_KC16=1 lets 3-tap (or fewer) launches on the 128x128 tile use 16-channel chunks
+    static const bool kc16_env = getenv("VFX_KC16") && atoi(getenv("VFX_KC16")) != 0;
     ConvTables tb;
-    int KC = 8;
+    int KC = (kc16_env && maxnt <= 3 && tc.BM == 128 && tc.BL == 128 && !waves8 && Cin % 16 == 0) ? 16 : 8;
     for (;;) {
         std::memset(&tb, 0, sizeof(tb));
         int rc = fill_segments(a, tb, nphase, phs, tc.BL, KC);
@@ -671,10 +673,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         int maxseg = 0;
         for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
         const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * nthr;
-        const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 8 ? 4 : 5) * 4 * nthr;
+        const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 16 ? 6 : (KC == 8 ? 4 : 5)) * 4 * nthr;
         if (xfit && wfit) break;
         if (KC == 4) return VFX_ERANGE;
-        KC = 4;
+        KC = KC == 16 ? 8 : 4;
     }
     a.tab = device_tables(tb);
     if (!a.tab) return VFX_EINVAL;
@@ -715,6 +717,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         a.tpw = 1;  // multi-tile workgroups measured slower (register pressure), see the kernel comment
     }
     const int gy = nphase * Cout / tc.BM;
+    if (KC == 16) return launch_cfg<128, 128, 2, 2, 16>(a, ntiles, gy, B, lds, stream);
 #define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                    \
     if (tc.BM == BM_ && tc.BL == BL_)                                                     \
         return KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, ntiles, gy, B, lds, stream) \
