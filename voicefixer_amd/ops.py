@@ -186,8 +186,13 @@ def stft_mel(wav, mel, N):
     _need_cuda(wav, mel)
     frontend_init()
     assert wav.stride(1) == 1 and mel.is_contiguous()
+    e0 = _prof_begin()
     check(_lib.lib().vfx_stft_mel_f32(_ptr(wav), wav.stride(0), wav.shape[0], N, _ptr(mel), _stream()),
           "vfx_stft_mel_f32")
+    if e0 is not None:  # bench.py: HBM roofline of the front-end, algorithmic bytes 4*N + 512*T per utterance
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((-1, wav.shape[0] * (4 * N + 512 * (1 + N // 441)), e0, e1))
 
 
 _oracle_ready = False
