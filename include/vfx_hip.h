@@ -198,6 +198,15 @@ void vfx_gru_layout(int* kreg, int* klds, int* kstr);
 int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const float* bhh,
                       const vfx_tensor* out, int B, int T, vfx_stream_t stream);
 
+/* Same recurrence with every sequence owned by a PAIR of workgroups (one CU each) that keep W_hh
+ * entirely in registers and exchange partial gate sums through tagged 8-byte granules: ~2x faster
+ * per step, needs 4*B <= 240 workgroups to be co-resident (split larger batches).  whh_t = plain
+ * [2][256][768] (W_hh transposed per direction); mailbox = B*24576 device bytes (zeroed by the call);
+ * err_flag = device int32, set to 1 if a partner never answered (bounded spin, never hangs). */
+int vfx_gru_bidir2_f32(const float* gi, const float* whh_t, const float* bhh, const vfx_tensor* out,
+                       int B, int T, void* mailbox, size_t mailbox_bytes, int32_t* err_flag,
+                       vfx_stream_t stream);
+
 /* ---- synthesis front/back -------------------------------------------------------- */
 
 /* mel (B,T,128) linear -> cond (B,128,T') channel-major, T' = T + T%2 + 4, tail = -4.0:

@@ -62,6 +62,7 @@ def test_restore_golden(pipe, name):
     assert np.abs(logmel.cpu().numpy() - g["logmel"][:, 0]).max() < 2e-4
     out = pipe.restore(wav, N)
     torch.cuda.synchronize()
+    assert int(pipe.restorer.gru_err.item()) == 0  # two-CU GRU hand-off never timed out
     got = out.cpu().numpy()
     assert got.shape == g["restored"].shape
     r = _rms(got, g["restored"])

@@ -320,6 +320,33 @@ def test_gru_bidir():
     _close(out[:, :, :T].transpose(1, 2), ref, 1e-5)
 
 
+def test_gru_bidir_two_cu():
+    B, T = 5, 61
+    x = _rand((B, T, 512), 60)
+    g = torch.Generator().manual_seed(61)
+    P = {}
+    for suf in ("", "_reverse"):
+        P["w_ih" + suf] = (torch.rand((768, 512), generator=g) * 2 - 1) / 16
+        P["w_hh" + suf] = (torch.rand((768, 256), generator=g) * 2 - 1) / 16
+        P["b_ih" + suf] = (torch.rand((768,), generator=g) * 2 - 1) / 16
+        P["b_hh" + suf] = (torch.rand((768,), generator=g) * 2 - 1) / 16
+    outs, gis = [], []
+    for suf, rev in (("", False), ("_reverse", True)):
+        outs.append(oracle._gru_dir(x, P["w_ih" + suf], P["w_hh" + suf], P["b_ih" + suf], P["b_hh" + suf], rev))
+        gis.append(x @ P["w_ih" + suf].t() + P["b_ih" + suf])
+    ref = torch.cat(outs, -1)
+    gi = torch.cat(gis, -1).contiguous().to(DEV)
+    whh_t = torch.stack([P["w_hh"].t().contiguous(), P["w_hh_reverse"].t().contiguous()]).to(DEV)
+    bhh = torch.stack([P["b_hh"], P["b_hh_reverse"]]).to(DEV)
+    out = torch.full((B, 512, 64), float("nan"), device=DEV)
+    err = torch.zeros(1, dtype=torch.int32, device=DEV)
+    keep = ops.gru_bidir2(gi, whh_t, bhh, out, T, err)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0, "partner workgroup never answered"
+    _close(out[:, :, :T].transpose(1, 2), ref, 1e-5)
+    del keep
+
+
 def test_mel_to_cond():
     g = torch.Generator().manual_seed(34)
     for T in (101, 24):

@@ -20,3 +20,16 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
 print("gru B=%d T=%d layout=%s: %.3f ms/launch, %.2f us/step" % (B, T, ops.gru_layout(), ms, ms * 1e3 / T))
+
+if B <= ops.GRU2_MAX_B:
+    wt = torch.randn((2, 256, 768), generator=g).cuda() / 16
+    err = torch.zeros(1, dtype=torch.int32).cuda()
+    keep = ops.gru_bidir2(gi, wt, bhh, out, T, err)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        keep = ops.gru_bidir2(gi, wt, bhh, out, T, err)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 3
+    print("gru2 (two CUs per sequence) B=%d: %.3f ms/launch, %.2f us/step, err=%d" % (B, ms, ms * 1e3 / T, int(err.item())))

@@ -59,6 +59,7 @@ SIGNATURES = {
     "vfx_unet_input_f32": (_I, [_P, _T, _T, _I, _I, _I, _I, _P]),
     "vfx_unet_output_f32": (_I, [_T, _T, _P, _T, _P, _P, _I, _I, _I, _P]),
     "vfx_gru_bidir_f32": (_I, [_P, _P, _P, _T, _I, _I, _P]),
+    "vfx_gru_bidir2_f32": (_I, [_P, _P, _P, _T, _I, _I, _P, C.c_size_t, _P, _P]),
     "vfx_gru_layout": (None, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "vfx_mel_to_cond_f32": (_I, [_P, _T, _I, _I, _P]),
     "vfx_post_f32": (_I, [_P, C.c_int64, _I, _P, C.c_int64, _I, _I, _P, _P]),

@@ -202,3 +202,151 @@ extern "C" void vfx_gru_layout(int* kreg, int* klds, int* kstr) {
     *klds = GRU_KLDS;
     *kstr = GRU_KSTR;
 }
+
+// ======================================================================================
+// Two-CU variant: each (utterance, direction) sequence is owned by a PAIR of workgroups.
+// Workgroup r holds the k-half r of W_hh^T entirely in registers (64 k x 3 gate rows per thread,
+// 512 threads) -- nothing is streamed from L2 any more, which is what bounds the one-workgroup
+// kernel (384 KB per step at the per-CU L2 rate).  Per step each workgroup computes the partial
+// gate pre-activations over its k-half for all 768 rows, keeps the 384 that belong to "its" hidden
+// units (units 128r .. 128r+127 == its own k range, so h never has to travel) and hands the other
+// 384 to its partner through 8-byte {tag = step+1, value} granules written with ONE agent-scope
+// relaxed store each (MI355X guide, hand-off recipe R2: the data is the flag, no fence).  The
+// receiver polls with relaxed agent-scope loads.  Mailboxes are zeroed by a memset node before every
+// launch; spins are bounded and raise a device flag instead of hanging.
+// Residency: partners have adjacent block ids and the host never launches more workgroups than CUs.
+// ======================================================================================
+typedef unsigned long long u64;
+#define G2_SPIN_LIMIT (1u << 24)
+
+__global__ __launch_bounds__(512, 2) void gru2_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
+                                                      const float* __restrict__ bhh, float* __restrict__ out,
+                                                      long long o_bs, long long o_cs, int T, u64* __restrict__ mbox,
+                                                      int* __restrict__ err) {
+    __shared__ float hloc[2][128];
+    __shared__ float part[3][256];
+    const int tid = threadIdx.x;
+    const int j = tid & 255, kq = tid >> 8;
+    const int wg = blockIdx.x;
+    const int r = wg & 1, pair = wg >> 1;
+    const int dir = pair & 1, b = pair >> 1;
+    const float* W = whh_t + (long long)dir * GRU_H * GRU_G + (long long)(r * 128 + kq * 64) * GRU_G;
+    const float* g = gi + (long long)b * T * (2 * GRU_G) + dir * GRU_G;
+    const bool mine = (j >> 7) == r;       // unit j is finalised by this workgroup
+    const int ju = j & 127;
+    float* o = out + (long long)b * o_bs + (long long)(dir * GRU_H + j) * o_cs;
+    // mailbox of workgroup (pair, r): [slot 2][384] granules, written by the partner
+    u64* my_box = mbox + ((long long)pair * 2 + r) * 2 * 384;
+    u64* peer_box = mbox + ((long long)pair * 2 + (r ^ 1)) * 2 * 384;
+
+    float wr[64], wz[64], wn[64];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        wr[k] = W[k * GRU_G + j];
+        wz[k] = W[k * GRU_G + GRU_H + j];
+        wn[k] = W[k * GRU_G + 2 * GRU_H + j];
+    }
+    float br = 0.f, bz = 0.f, bn = 0.f, hj = 0.f;
+    if (kq == 0 && mine) {
+        br = bhh[dir * GRU_G + j];
+        bz = bhh[dir * GRU_G + GRU_H + j];
+        bn = bhh[dir * GRU_G + 2 * GRU_H + j];
+    }
+    if (tid < 256) hloc[tid >> 7][tid & 127] = 0.f;
+    __syncthreads();
+
+    int t = dir ? T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float gr = 0.f, gz = 0.f, gn = 0.f;
+    if (kq == 0 && mine) {
+        gr = g[(long long)t * (2 * GRU_G) + j];
+        gz = g[(long long)t * (2 * GRU_G) + GRU_H + j];
+        gn = g[(long long)t * (2 * GRU_G) + 2 * GRU_H + j];
+    }
+    bool failed = false;
+
+    for (int s = 0; s < T; ++s) {
+        const float* h = hloc[s & 1] + kq * 64;
+        const int tn = t + dt;
+        float ngr = 0.f, ngz = 0.f, ngn = 0.f;
+        if (kq == 0 && mine && s + 1 < T) {
+            ngr = g[(long long)tn * (2 * GRU_G) + j];
+            ngz = g[(long long)tn * (2 * GRU_G) + GRU_H + j];
+            ngn = g[(long long)tn * (2 * GRU_G) + 2 * GRU_H + j];
+        }
+        float ar = 0.f, az = 0.f, an = 0.f;
+#pragma unroll
+        for (int k = 0; k < 64; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(h + k);
+            ar = fmaf(wr[k], hv.x, ar); az = fmaf(wz[k], hv.x, az); an = fmaf(wn[k], hv.x, an);
+            ar = fmaf(wr[k + 1], hv.y, ar); az = fmaf(wz[k + 1], hv.y, az); an = fmaf(wn[k + 1], hv.y, an);
+            ar = fmaf(wr[k + 2], hv.z, ar); az = fmaf(wz[k + 2], hv.z, az); an = fmaf(wn[k + 2], hv.z, an);
+            ar = fmaf(wr[k + 3], hv.w, ar); az = fmaf(wz[k + 3], hv.w, az); an = fmaf(wn[k + 3], hv.w, an);
+            if ((k & 15) == 12) __builtin_amdgcn_sched_barrier(0);
+        }
+        if (kq == 1) {
+            part[0][j] = ar;
+            part[1][j] = az;
+            part[2][j] = an;
+        }
+        __syncthreads();
+        if (kq == 0) {
+            ar += part[0][j];
+            az += part[1][j];
+            an += part[2][j];
+            const unsigned tag = (unsigned)(s + 1);
+            const int slot = (s & 1) * 384;
+            if (!mine) {
+                // hand the partials of the partner's units over: one 8-byte sc1 store per value
+                u64* dst = peer_box + slot + ju * 3;
+                __hip_atomic_store(dst + 0, ((u64)tag << 32) | __float_as_uint(ar), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 1, ((u64)tag << 32) | __float_as_uint(az), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + 2, ((u64)tag << 32) | __float_as_uint(an), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                const u64* src = my_box + slot + ju * 3;
+                float pv[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    u64 v = 0;
+                    unsigned spins = 0;
+                    for (;;) {
+                        v = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((unsigned)(v >> 32) == tag) break;
+                        if (++spins > G2_SPIN_LIMIT) { failed = true; break; }
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                    pv[q] = __uint_as_float((unsigned)v);
+                }
+                ar += pv[0] + br;
+                az += pv[1] + bz;
+                an += pv[2] + bn;
+                const float rr = 1.f / (1.f + expf(-(gr + ar)));
+                const float zz = 1.f / (1.f + expf(-(gz + az)));
+                const float nn = tanhf(gn + rr * an);
+                hj = (1.f - zz) * nn + zz * hj;
+                hloc[(s + 1) & 1][ju] = hj;
+                o[t] = hj;
+                gr = ngr; gz = ngz; gn = ngn;
+            }
+        }
+        t = tn;
+        if (__syncthreads_or(failed ? 1 : 0)) break;  // barrier + uniform exit if any lane timed out
+    }
+    if (failed) atomicExch(err, 1);
+}
+
+extern "C" int vfx_gru_bidir2_f32(const float* gi, const float* whh_t, const float* bhh, const vfx_tensor* out, int B,
+                                  int T, void* mailbox, size_t mailbox_bytes, int32_t* err_flag, vfx_stream_t stream) {
+    if (!gi || !whh_t || !bhh || !out || !out->ptr || !mailbox || !err_flag || B <= 0 || T <= 0) return VFX_EINVAL;
+    if (out->lstride != 1) return VFX_EALIGN;
+    if (B * 4 > 240) return VFX_ERANGE;  // every workgroup must be resident (one per CU, 256 CUs)
+    const size_t need = (size_t)B * 2 * 2 * 2 * 384 * sizeof(u64);
+    if (mailbox_bytes < need) return VFX_ERANGE;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(mailbox, 0, need, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(gru2_kernel, dim3(B * 4), dim3(512), 0, s, gi, whh_t, bhh, (float*)out->ptr, out->bstride,
+                       out->cstride, T, (u64*)mailbox, (int*)err_flag);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}

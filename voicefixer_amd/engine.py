@@ -208,7 +208,8 @@ class RestorerEngine:
                     bhh.append(f(p + "bias_hh_l%d%s" % (layer, suf)))
                 layers.append((_dev(packing.pack_linear(torch.cat(Ws, 0)), device), _dev(torch.cat(bs, 0), device),
                                _dev(packing.pack_gru_whh(whh[0], whh[1], *ops.gru_layout()), device),
-                               _dev(torch.stack(bhh), device)))
+                               _dev(torch.stack(bhh), device),
+                               _dev(torch.stack([whh[0].t().contiguous(), whh[1].t().contiguous()]), device)))
             self.grus.append(layers)
         a4, b4 = bn_scalar("denoiser.9")
         a5, b5 = bn_scalar("denoiser.13")
@@ -219,6 +220,8 @@ class RestorerEngine:
         self.l4 = (_dev(packing.pack_linear(f("denoiser.15.weight")), device), _dev(f("denoiser.15.bias"), device))
         self.act_relu = ops.Act(post=POST_LRELU, post_slope=0.0)
         self.act_sigmoid = ops.Act(post=POST_SIGMOID)
+        self.gru_err = None   # device flag: set by vfx_gru_bidir2_f32 if a partner workgroup timed out
+        self._gru_keep = []
 
         self.enc = []
         for b in range(1, 7):
@@ -249,12 +252,22 @@ class RestorerEngine:
         x = _rows(B, 512, T, G_TILE, dev)
         ops.conv1d(x1, self.l2[0], self.l2[1], x, T, 1, act=self.act_relu)
         gi = torch.empty((B, T, 1536), device=dev)
+        if self.gru_err is None:
+            self.gru_err = torch.zeros(1, dtype=torch.int32, device=dev)
+        keep = []
         for layers in self.grus:
-            for (wih, bih, whh, bhh) in layers:
+            for (wih, bih, whh_packed, bhh, whh_t) in layers:
                 ops.conv1d(x, wih, bih, gi.transpose(1, 2), T, 1)
                 y = _rows(B, 512, T, G_TILE, dev)
-                ops.gru_bidir(gi, whh, bhh, y, T)
+                # two CUs per sequence (W_hh resident in registers) while all 4*B workgroups fit on the
+                # chip; larger batches are walked in resident-sized groups
+                for b0 in range(0, B, ops.GRU2_MAX_B):
+                    b1 = min(B, b0 + ops.GRU2_MAX_B)
+                    yv = y[b0:b1]
+                    yv._vfx_guard = getattr(y, "_vfx_guard", 0)
+                    keep.append(ops.gru_bidir2(gi[b0:b1], whh_t, bhh, yv, T, self.gru_err))
                 x = y
+        self._gru_keep = keep  # mailboxes stay referenced until the next forward
         x3 = _rows(B, 512, T, G_TILE, dev)
         ops.conv1d(x, self.l3[0], self.l3[1], x3, T, 1, act=self.act_l3)
         mask = torch.empty((B, 128, Tp4), device=dev)

@@ -279,6 +279,22 @@ def gru_bidir(gi, whh_t, bhh, out, T):
           "vfx_gru_bidir_f32")
 
 
+GRU2_MAX_B = 32  # 4 workgroups per utterance, all resident; 128 per launch so that two streams' launches still fit 256 CUs
+
+
+def gru_bidir2(gi, whh_t, bhh, out, T, err_flag):
+    """Two-CU-per-sequence GRU (vfx_gru_bidir2_f32).  whh_t: plain (2,256,768); err_flag: device int32[1]."""
+    _need_cuda(gi, whh_t, bhh, out, err_flag)
+    B = gi.shape[0]
+    assert B <= GRU2_MAX_B
+    nbytes = B * 2 * 2 * 2 * 384 * 8
+    mbox = torch.empty((nbytes // 4,), dtype=torch.int32, device=gi.device)
+    od = tdesc(out)
+    check(_lib.lib().vfx_gru_bidir2_f32(_ptr(gi), _ptr(whh_t), _ptr(bhh), C.byref(od), B, T, _ptr(mbox), nbytes,
+                                        _ptr(err_flag), _stream()), "vfx_gru_bidir2_f32")
+    return mbox  # keep alive until the stream has consumed it (caller holds the reference)
+
+
 def mel_to_cond(mel, cond, T):
     _need_cuda(mel, cond)
     assert mel.is_contiguous()
