@@ -144,6 +144,34 @@ __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const C
     for (int j = 0; j < MAXWV; ++j) st.wv[j] = *reinterpret_cast<const float4*>(wc + st.w_off[j]);
 }
 
+// Interior tile of a launch without BatchNorm pre-activation / pad-column mask (every vocoder and
+// denoiser layer): the activation is at most a leaky-ReLU, no predicate of any kind is needed.
+template <int NTHR, int MAXXV, int MAXWV>
+__device__ __forceinline__ void stage_write_plain(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, float* xs, float* ws,
+                                                  int nxv, int nwv, int xtotal, int wtotal, int tid) {
+    const float slope = a.pre_act == VFX_PRE_LRELU ? a.pre_slope : 1.f;
+#pragma unroll
+    for (int j = 0; j < MAXXV; ++j) {
+        if (j < nxv) {
+            float4 v = st.xv[j];
+            v.x = v.x > 0.f ? v.x : v.x * slope;
+            v.y = v.y > 0.f ? v.y : v.y * slope;
+            v.z = v.z > 0.f ? v.z : v.z * slope;
+            v.w = v.w > 0.f ? v.w : v.w * slope;
+            int i = tid + NTHR * j;
+            i = i < xtotal ? i : xtotal - 1;
+            *reinterpret_cast<float4*>(xs + 4 * i) = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXWV; ++j)
+        if (j < nwv) {
+            int i = tid + NTHR * j;
+            i = i < wtotal ? i : wtotal - 1;
+            *reinterpret_cast<float4*>(ws + 4 * i) = st.wv[j];
+        }
+}
+
 template <bool FAST, int NTHR, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, int c0, float* xs,
                                             float* ws, const float* aff, int nxv, int nwv, int xtotal,
@@ -183,7 +211,11 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                         if (l + k < 0 || l + k >= a.Lin) e[k] = 0.f;
                 }
             }
-            if (in_mask) {
+            if (in_mask >= 3) {
+                // pitch >= 4 and l % 4 == 0: only the last element of a vector can sit on the pad column
+                const int l = st.x_l[j] + lshift;
+                if (((l + 3) & in_mask) == in_mask) e[3] = 0.f;
+            } else if (in_mask) {
                 const int l = st.x_l[j] + lshift;
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
@@ -394,7 +426,9 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
             range_mask |= (o < 0) || (o + segw > a.Lin);
         }
     }
-    stage_write<FAST, NTHR>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
+    const bool plain = FAST && !range_mask && a.in_mask == 0 && a.pre_act != VFX_PRE_AFFINE_LRELU;
+    if (plain) stage_write_plain<NTHR>(st, a, smem, smem + a.xs_floats, nxv, nwv, xtotal, wtotal, tid);
+    else stage_write<FAST, NTHR>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
     if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0);
     __syncthreads();
 #if VFX_ABL & 8
@@ -408,8 +442,9 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 #if !(VFX_ABL & 1)
         if (s + 1 < S) {
             float* nxs = smem + ((s + 1) & 1) * bufstride;
-            stage_write<FAST, NTHR>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, ti1 * BL,
-                              range_mask);
+            if (plain) stage_write_plain<NTHR>(st, a, nxs, nxs + a.xs_floats, nxv, nwv, xtotal, wtotal, tid);
+            else stage_write<FAST, NTHR>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid,
+                                         ti1 * BL, range_mask);
 #if VFX_ABL & 8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
