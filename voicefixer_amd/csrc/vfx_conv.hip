@@ -34,6 +34,7 @@
 #define VFX_MAXT 9
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #if VFX_ABL & 8
 // development: per-phase cycle totals (wave 0 of every workgroup), read back with vfx_debug_read
@@ -80,6 +81,7 @@ struct ConvArgs {
     int in_mask, out_mask;  // pitch-1 (e.g. 127) or 0: positions with (l & mask) == mask are structural zeros
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
+    int x_guard;            // readable elements before every input row (vfx_tensor.guard)
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -106,7 +108,24 @@ struct StageState {
 // loads, no per-element range logic, no branches.  Boundary tiles run the general instance.
 template <bool FAST, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const ConvArgs& a,
-                                           const float* __restrict__ xb, int xcs, int c0, int lshift) {
+                                           const float* __restrict__ xb, int xcs, int c0, int lshift,
+                                           __amdgpu_buffer_rsrc_t xrsrc, __amdgpu_buffer_rsrc_t wrsrc) {
+    if constexpr (FAST) {
+        // buffer loads: per-slot byte offset in one VGPR (fixed for the whole K loop) + the chunk's offset
+        // in an SGPR -> no 64-bit address arithmetic per load
+        const int xso = (c0 * xcs + lshift) * 4, wso = c0 * a.Cout * 4;
+#pragma unroll
+        for (int j = 0; j < MAXXV; ++j) {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, st.x_off[j], xso, 0);
+            st.xv[j] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+        }
+#pragma unroll
+        for (int j = 0; j < MAXWV; ++j) {
+            const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, st.w_off[j], wso, 0);
+            st.wv[j] = make_float4(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
+        }
+        return;
+    }
     const float* __restrict__ xc = xb + (long long)c0 * xcs + lshift;
     const float* __restrict__ wc = a.w + (long long)c0 * a.Cout;
 #pragma unroll
@@ -373,7 +392,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
         const int v = rem - kc * sv;
         st.x_kc[j] = kc;
         st.x_l[j] = q0 + pt->seg_org[s] + 4 * v;
-        st.x_off[j] = kc * xcs + st.x_l[j];
+        st.x_off[j] = FAST ? (kc * xcs + st.x_l[j] + a.x_guard) * 4 : kc * xcs + st.x_l[j];
     }
 #pragma unroll
     for (int j = 0; j < MAXWV; ++j) {
@@ -383,7 +402,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
         const int rem = i - t * (KC * (BM / 4));
         const int kc = rem / (BM / 4);
         const int v = rem - kc * (BM / 4);
-        st.w_off[j] = (pt->tap_w[t] * a.CinPad + kc) * a.Cout + m0 + 4 * v;
+        st.w_off[j] = ((pt->tap_w[t] * a.CinPad + kc) * a.Cout + m0 + 4 * v) * (FAST ? 4 : 1);
     }
 
     f32x16 acc[RM][RL];
@@ -409,6 +428,10 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
         }
         __syncthreads();
     }
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xb) - a.x_guard, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), (short)0, 0x7fffffff, 0x00020000);
     // Software pipeline over the K chunks, two steps deep: at the top of step s the registers hold
     // chunk s+1 (loaded a whole step ago, so the wait is free); they are written to the other LDS
     // buffer, the loads of chunk s+2 are issued, and only then the MFMAs of chunk s run.  One barrier
@@ -417,7 +440,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     const int S = nchunks;
     int ch1 = 1, ch2 = 2;  // chunk held in registers / chunk being loaded at the top of step s
     constexpr int ti1 = 0, ti2 = 0;
-    stage_load<FAST>(st, a, xb, xcs, 0, 0);
+    stage_load<FAST>(st, a, xb, xcs, 0, 0, xrsrc, wrsrc);
     // does any staged vector of this tile leave [0, Lin)?  (uniform; only possible with a guard band)
     bool range_mask = false;
     if constexpr (FAST) {
@@ -429,7 +452,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     const bool plain = FAST && !range_mask && a.in_mask == 0 && a.pre_act != VFX_PRE_AFFINE_LRELU;
     if (plain) stage_write_plain<NTHR>(st, a, smem, smem + a.xs_floats, nxv, nwv, xtotal, wtotal, tid);
     else stage_write<FAST, NTHR>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
-    if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0);
+    if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0, xrsrc, wrsrc);
     __syncthreads();
 #if VFX_ABL & 8
     unsigned long long d_write = 0, d_load = 0, d_mfma = 0, d_bar = 0;
@@ -451,7 +474,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
         }
         DBG_T(t1);
         if (s + 1 < S) {
-            if (s + 2 < S) stage_load<FAST>(st, a, xb, xcs, ch2 * KC, ti2 * BL);
+            if (s + 2 < S) stage_load<FAST>(st, a, xb, xcs, ch2 * KC, ti2 * BL, xrsrc, wrsrc);
         }
 #endif
         DBG_T(t2);
@@ -658,6 +681,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     a.B = B; a.Cin = Cin; a.CinPad = (Cin + 7) & ~7; a.Cout = Cout;
     a.Lin = Lin; a.Lq = Lq; a.Lout = Lout;
     a.x_bs = x->bstride; a.x_cs = x->cstride;
+    a.x_guard = (x->guard > 0 && pad_mode != VFX_PAD_REFLECT) ? (int)x->guard : 0;
     a.y_bs = y->bstride; a.y_cs = y->cstride; a.y_ls = y->lstride;
     if (res) { a.r_bs = res->bstride; a.r_cs = res->cstride; a.r_ls = res->lstride; }
     a.q_shift = q_shift; a.q_mask = q_mask; a.o_rs = o_rs; a.o_cs = o_cs;
