@@ -112,3 +112,17 @@ def test_linearity_free_properties(pipe):
 def test_short_segment_raises(pipe):
     with pytest.raises(_lib.VfxError):
         pipe.restore(torch.zeros((1, 1000), device="cuda"), 1000)
+
+
+@pytest.mark.parametrize("n", [1025, 2047, 3001, 7777, 12345])
+def test_restore_ragged_lengths_vs_oracle(pipe, seeded_states, n):
+    """Shortest legal segment (1025 samples = one reflect pad) and odd lengths: every tile / guard /
+    tail-padding combination of the launch plans against the CPU oracle."""
+    g = torch.Generator().manual_seed(n)
+    wav = 0.2 * torch.randn(n, generator=g)
+    out = pipe.restore(wav[None].cuda(), n)
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = oracle.restore_inmem(wav.numpy(), seeded_states[0], seeded_states[1])
+    assert out.shape == (1, n)
+    assert _rms(out.cpu().numpy(), ref) < RMS_TOL
