@@ -143,3 +143,28 @@ def test_mode1_matches_oracle(vf):
         ref = oracle.restore_inmem(filt, *_states(vf))
     assert out.shape == ref.shape == (1, 512 * (len(wav) // 512))
     assert _rms(out, ref) < 1e-4
+
+
+def test_restore_folder_matches_per_file_restore(vf, tmp_path):
+    """Folder driver (voicefixer/__main__.py:176-212 semantics): every *.wav of the input folder appears
+    under the same name in the output folder and equals what restore() writes for that file alone
+    (two files share a length and are batched; one has another length; one is 22.05 kHz stereo)."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(5)
+    ind, outd, single = tmp_path / "in", tmp_path / "out", tmp_path / "single"
+    ind.mkdir(); single.mkdir()
+    for name, n in (("a.wav", 30000), ("b.wav", 30000), ("c.wav", 41000)):
+        audio_io.save_wave((0.2 * rng.standard_normal(n)).astype(np.float32)[None], str(ind / name))
+    st = (0.2 * rng.standard_normal((16000, 2)) * 32767).astype(np.int16)
+    wavfile.write(str(ind / "d.wav"), 22050, st)
+    (ind / "notes.txt").write_text("ignored")
+    files = vf.restore_folder(str(ind), str(outd), batch_size=4, io_threads=2)
+    assert files == ["a.wav", "b.wav", "c.wav", "d.wav"]
+    assert sorted(os.listdir(outd)) == files
+    for f in files:
+        vf.restore(input=str(ind / f), output=str(single / f), cuda=True, mode=0)
+        sr1, x1 = wavfile.read(str(outd / f))
+        sr2, x2 = wavfile.read(str(single / f))
+        assert sr1 == sr2 == 44100 and x1.shape == x2.shape and x1.dtype == np.int16
+        # batch-vs-single launches may pick different K-chunk depths (summation order): <= 1 LSB of PCM16
+        assert np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1

@@ -239,6 +239,33 @@ class VoiceFixer(nn.Module):
                 outs[k] = full[r:r + 1]
         return outs
 
+    def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None):
+        """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
+        ``infolder`` -> same file name in ``outfolder``), batched: files are decoded / resampled / down-mixed
+        by a thread pool, bucketed by length, restored ``batch_size`` at a time, and encoded to PCM16 by the
+        same pool while the next batch computes.  Returns the list of file names written."""
+        from concurrent.futures import ThreadPoolExecutor
+        self._check_mode(mode)
+        if mode != 0:
+            raise NotImplementedError("restore_folder batches mode 0; use restore() per file for mode 1")
+        files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] == ".wav")
+        os.makedirs(outfolder, exist_ok=True)
+        with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
+            wavs = list(pool.map(lambda f: audio_io.load_wav(os.path.join(infolder, f), 44100), files))
+            writes = []
+            order = sorted(range(len(files)), key=lambda i: len(wavs[i]))
+            # one restore_batch call per window of the length-sorted list keeps host memory bounded and lets
+            # the encoder threads of window k overlap the device work of window k+1
+            win = max(batch_size, 1) * 8
+            for w0 in range(0, len(order), win):
+                idx = order[w0:w0 + win]
+                outs = self.restore_batch([wavs[i] for i in idx], your_vocoder_func, batch_size)
+                for i, o in zip(idx, outs):
+                    writes.append(pool.submit(audio_io.save_wave, o, os.path.join(outfolder, files[i]), 44100))
+            for w in writes:
+                w.result()
+        return files
+
     def restore(self, input, output, cuda=False, mode=0, your_vocoder_func=None):
         wav_10k = self._load_wav(input, sample_rate=44100)
         out_np_wav = self.restore_inmem(wav_10k, cuda=cuda, mode=mode, your_vocoder_func=your_vocoder_func)
