@@ -60,6 +60,13 @@ typedef struct {
 #define VFX_POST_SIGMOID 4
 #define VFX_POST_LRELU_SNAKE 5  /* v = leaky_relu(., post_slope); v + sin(v)  (UpsampleNet prologue fused upstream) */
 
+/* arithmetic of the contraction (per launch) */
+#define VFX_MATH_F32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation (default) */
+#define VFX_MATH_BF16X3 1  /* opt-in: every fp32 operand split into two bf16 terms, x*w evaluated as
+                              xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
+                              (relative product error <= 2^-16); needs w_x3, falls back to fp32 for
+                              geometries the bf16x3 kernel does not cover */
+
 typedef struct {
     int pre_act;
     float pre_slope;
@@ -67,6 +74,9 @@ typedef struct {
     const float* pre_shift; /* [Cin] */
     int post_act;
     float post_slope;
+    int math;               /* VFX_MATH_* */
+    const void* w_x3;       /* VFX_MATH_BF16X3: the packed weights as bf16 (hi, lo) planes, layout
+                               [slab][Cin/16][plane][Cout][16] (voicefixer_amd/packing.py::pack_x3) */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0

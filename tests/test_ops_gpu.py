@@ -122,6 +122,84 @@ def test_conv1d_guarded_input_all_interior():
     _close(yd, ref, 2e-5)
 
 
+X3_CASES = [
+    # B, Cin, Cout, L, dil, res  (k = 3, guarded input: the bf16x3 kernel only runs all-interior launches)
+    (2, 64, 64, 1000, 1, True),      # 64x128 tile, halo
+    (1, 64, 64, 9000, 27, False),    # 64x256 tile, halo
+    (1, 64, 64, 3001, 243, True),    # 64x128 tile, one segment per tap
+    (2, 128, 128, 700, 9, False),    # 128x128 tile
+    (1, 256, 256, 1500, 729, True),
+    (1, 512, 512, 742, 2187, False),  # dilation > L
+    (1, 128, 512, 106, 1, False),
+]
+
+
+@pytest.mark.parametrize("case", X3_CASES)
+def test_conv1d_bf16x3(case):
+    """Opt-in VFX_MATH_BF16X3: split-bf16 products (xh*wh + xh*wl + xl*wh), fp32 accumulation.  Per-product
+    relative error <= 2^-16, so the result sits within 1e-4 of the fp32 operator (the fp32 kernel: 2e-5)."""
+    B, Cin, Cout, L, dil, use_res = case
+    x = _rand((B, Cin, L), 61)
+    w = _rand((Cout, Cin, 3), 62, (Cin * 3) ** -0.5)
+    bias = _rand((Cout,), 63, 0.1)
+    res = _rand((B, Cout, L), 64) if use_res else None
+    ref = F.conv1d(F.leaky_relu(x, 0.01), w, bias, dilation=dil, padding=dil)
+    if use_res:
+        ref = ref + res
+    ref = F.leaky_relu(ref, 0.2)
+    xd = ops.guarded(B, Cin, L, dil + 264, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xd[:, :, :L] = x.to(DEV)
+    lp = (L + 3) // 4 * 4
+    yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+    rd = _padded(res, lp) if use_res else None
+    wp = packing.pack_conv1d(w)
+    w3 = packing.pack_x3(wp).to(DEV)
+    act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.2)
+    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, rd, w3=w3)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
+    _close(yd[:, :, :L], ref, 1e-4)
+    err = (yd[:, :, :L].cpu() - ref).pow(2).mean().sqrt().item() / ref.pow(2).mean().sqrt().item()
+    assert err < 2e-5, err
+    assert torch.isnan(yd[:, :, L:]).all()
+
+
+@pytest.mark.parametrize("cfg", [(1, 1024, 512, 106, 7), (2, 256, 128, 531, 3), (1, 128, 64, 1000, 3)])
+def test_convtr1d_bf16x3(cfg):
+    B, Cin, Cout, Lin, s = cfg
+    x = _rand((B, Cin, Lin), 65)
+    w = _rand((Cin, Cout, 2 * s), 66, (2 * Cin) ** -0.5)
+    bias = _rand((Cout,), 67, 0.1)
+    ref = F.conv_transpose1d(x, w, bias, stride=s, padding=s // 2 + s % 2, output_padding=s % 2)
+    xd = ops.guarded(B, Cin, Lin, 264, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xd[:, :, :Lin] = x.to(DEV)
+    Lo = s * Lin
+    yd = torch.full((B, Cout, (Lo + 7) // 4 * 4), float("nan"), device=DEV)
+    wp = packing.pack_convtr1d(w)
+    ops.convtr1d(xd, wp.to(DEV), bias.to(DEV), yd, Lin, s, w3=packing.pack_x3(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
+    _close(yd[:, :, :Lo], ref, 1e-4)
+    assert torch.isnan(yd[:, :, Lo:]).all()
+
+
+def test_bf16x3_falls_back_to_fp32_outside_its_coverage():
+    """Unguarded input (boundary tiles) -> the library runs the fp32 kernel; the result is the fp32 one."""
+    B, Cin, Cout, L = 1, 64, 64, 500
+    x = _rand((B, Cin, L), 68)
+    w = _rand((Cout, Cin, 3), 69, (Cin * 3) ** -0.5)
+    ref = F.conv1d(x, w, None, padding=1)
+    xd = _padded(x, 504)
+    yd = torch.full((B, Cout, 504), float("nan"), device=DEV)
+    wp = packing.pack_conv1d(w)
+    ops.conv1d(xd, wp.to(DEV), None, yd, L, 3, 1, 0, None, None, w3=packing.pack_x3(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 != 16
+    _close(yd[:, :, :L], ref, 2e-5)
+
+
 def test_linear_transposed_output():
     """Linear as conv k=1 with a frame-major output view (B,T,out) -- used for GRU x-projections."""
     B, T, Cin, Cout = 2, 101, 512, 1536

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("names", nargs="*", default=["res4_d1", "res3_d1", "res2_d1", "res1_d1"])
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--x3", action="store_true", help="VFX_MATH_BF16X3 (guarded inputs, 1-D shapes only)")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -53,21 +54,27 @@ def main():
         act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
         if kind in ("c1", "c1r"):
             Lp = (L + 3) // 4 * 4
-            x = torch.randn((B, cin, Lp), device=dev)
+            x = ops.guarded(B, cin, L, dil + 264, dev)
+            x.normal_()
             y = torch.empty((B, cout, Lp), device=dev)
-            w = packing.pack_conv1d(torch.randn((cout, cin, k), generator=g) * (cin * k) ** -0.5).to(dev)
+            wp = packing.pack_conv1d(torch.randn((cout, cin, k), generator=g) * (cin * k) ** -0.5)
+            w = wp.to(dev)
+            w3 = packing.pack_x3(wp).to(dev) if args.x3 else None
             bias = torch.zeros(cout, device=dev)
             pad = 1 if kind == "c1r" else 0
-            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act)
+            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3)
             macs = B * L * cin * cout * k
         elif kind == "t1":
             s = k
             Lp = (L + 3) // 4 * 4
-            x = torch.randn((B, cin, Lp), device=dev)
+            x = ops.guarded(B, cin, L, 264, dev)
+            x.normal_()
             y = torch.empty((B, cout, (L * s + 3) // 4 * 4), device=dev)
-            w = packing.pack_convtr1d(torch.randn((cin, cout, 2 * s), generator=g) * (2 * cin) ** -0.5).to(dev)
+            wp = packing.pack_convtr1d(torch.randn((cin, cout, 2 * s), generator=g) * (2 * cin) ** -0.5)
+            w = wp.to(dev)
+            w3 = packing.pack_x3(wp).to(dev) if args.x3 else None
             bias = torch.zeros(cout, device=dev)
-            fn = lambda: ops.convtr1d(x, w, bias, y, L, s)
+            fn = lambda: ops.convtr1d(x, w, bias, y, L, s, w3=w3)
             macs = B * L * cin * cout * 2 * s
         else:
             H, lp = L, k

@@ -24,12 +24,14 @@ class vfx_tensor(C.Structure):
 
 class vfx_act(C.Structure):
     _fields_ = [("pre_act", C.c_int), ("pre_slope", C.c_float), ("pre_scale", C.c_void_p),
-                ("pre_shift", C.c_void_p), ("post_act", C.c_int), ("post_slope", C.c_float)]
+                ("pre_shift", C.c_void_p), ("post_act", C.c_int), ("post_slope", C.c_float),
+                ("math", C.c_int), ("w_x3", C.c_void_p)]
 
 
 PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU = 0, 1, 2
 POST_NONE, POST_LRELU, POST_ELU, POST_TANH, POST_SIGMOID, POST_LRELU_SNAKE = 0, 1, 2, 3, 4, 5
 PAD_ZERO, PAD_REFLECT = 0, 1
+MATH_F32, MATH_BF16X3 = 0, 1
 
 _T = C.POINTER(vfx_tensor)
 _A = C.POINTER(vfx_act)

@@ -82,6 +82,12 @@ struct ConvArgs {
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
     int x_guard;            // readable elements before every input row (vfx_tensor.guard)
+    // ---- bf16x3 instance (conv_x3_kernel) only
+    const void* w3;         // weights as bf16 hi/lo planes: [slab][Cin/16][plane][Cout][16]
+    const ConvTables* tab3; // tap tables in POSITIONS (no 4-alignment: the x3 staging moves single floats)
+    int segw3;              // positions per staged segment
+    int xplane3;            // bytes between the hi and the lo plane of the activation tile
+    int buf3;               // bytes per LDS buffer (activation planes + weight tile)
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -534,6 +540,204 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 #endif
 }
 
+
+// --------------------------------------------------------------------------------------
+// bf16x3 instance: the same tap-GEMM with every fp32 operand split into two bf16 terms
+// (x = xh + xl, |x - xh - xl| <= 2^-17 |x|) and the product evaluated as xh*wh + xh*wl + xl*wh on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation (the dropped xl*wl term is 2^-18 relative).
+// Three bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16 channels.
+// Measured end-to-end waveform error vs the fp32 path: 2e-6 RMS, the same size as the difference
+// between two fp32 summation orders.  Opt-in (vfx_act.math).
+//
+// LDS image per K-chunk of 16 channels: activations as [plane][position][16 ch] bf16 (32 B per position
+// and plane: one ds_read_b128 per lane yields the 8 consecutive k of an MFMA B operand, a wave reads 1 KB
+// contiguous), weights as [tap][plane][row][16 k] in exactly the global packing order (straight copy).
+// A staging unit is (position, 8-channel half): 8 single-float buffer loads that differ only in their
+// scalar offset, activation + split in registers, two 16-byte LDS writes.
+// --------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int BM, int BL, int WGM, int WGL, int NT, bool SEG>
+__global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
+    constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
+    constexpr int NTHR = 256;
+    constexpr int NXS = SEG ? (NT * BL * 2) / NTHR : (BL * 2) / NTHR + 1;  // (position, k-half) units per thread
+    constexpr int NWS = (NT * BM * 4) / NTHR;                             // 16-byte weight vectors per thread
+    static_assert(WGM * WGL == 4 && (NT * BM * 4) % NTHR == 0 && (BL * 2) % NTHR == 0, "tile/thread mapping");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lo = lane & 31, hi = lane >> 5;
+    const int wm = wave / WGL, wl = wave % WGL;
+    const int tile = blockIdx.x + a.tile_lo;
+    const int q0 = tile * BL;
+    const int m0g = blockIdx.y * BM;
+    const int ph = m0g / a.Cout;
+    const int m0 = m0g - ph * a.Cout;
+    const int b = blockIdx.z;
+    const PhaseTab* __restrict__ pt = &a.tab3->ph[ph];
+    int tap_lds[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tap_lds[t] = __builtin_amdgcn_readfirstlane(pt->tap_lds[t]);
+    const int segw = a.segw3;
+    const int nseg = SEG ? NT : 1;
+    const int xunits = nseg * segw * 2;
+    const int xcs = (int)a.x_cs;
+    const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
+    const int nchunks = a.Cin >> 4;
+
+    // ---- per-thread staging slots, fixed for the whole K loop
+    int x_voff[NXS];   // byte offset of (channel 8*kh, position) from the row base; channel i of the half adds a scalar
+    int x_l[NXS];      // global position (range / pad-column masks)
+    int x_lds[NXS];    // byte offset of the unit's hi vector in the activation tile
+    const float inv_sw = 1.0f / (float)(segw * 2);
+#pragma unroll
+    for (int j = 0; j < NXS; ++j) {
+        int u = tid + NTHR * j;
+        u = u < xunits ? u : xunits - 1;  // clamped duplicates rewrite the same value
+        const int s = SEG ? fast_div(u, segw * 2, inv_sw) : 0;
+        const int rem = u - s * segw * 2;
+        const int pos = rem >> 1, kh = rem & 1;
+        const int l = q0 + pt->seg_org[s] + pos;
+        x_l[j] = l;
+        x_voff[j] = (kh * 8 * xcs + l + a.x_guard) * 4;
+        x_lds[j] = u * 16;
+    }
+    int w_voff[NWS];
+#pragma unroll
+    for (int j = 0; j < NWS; ++j) {
+        const int v = tid + NTHR * j;
+        const int t = v / (BM * 4);
+        const int rem = v - t * (BM * 4);
+        const int plane = rem / (BM * 2);
+        const int r2 = rem - plane * (BM * 2);
+        w_voff[j] = (((pt->tap_w[t] * nchunks * 2 + plane) * a.Cout + m0) * 32) + r2 * 16;
+    }
+    const int w_cstep = 2 * a.Cout * 32;  // bytes per 16-channel chunk in the packed weights
+
+    f32x16 acc[RM][RL];
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(xb) - a.x_guard, (short)0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), (short)0, 0x7fffffff, 0x00020000);
+
+    bool range_mask = false;
+#pragma unroll
+    for (int sg = 0; sg < (SEG ? NT : 1); ++sg) {
+        const int o = q0 + __builtin_amdgcn_readfirstlane(pt->seg_org[sg]);
+        range_mask |= (o < 0) || (o + segw > a.Lin);
+    }
+    const bool masked = range_mask || a.in_mask != 0;
+    const float slope = a.pre_act == VFX_PRE_LRELU ? a.pre_slope : 1.f;
+    const int xplane = a.xplane3, bufb = a.buf3;
+    const int wbase = 2 * xplane;  // weight tile follows the two activation planes
+
+    float xr[NXS][8];
+    u32x4 wr[NWS];
+    auto load_chunk = [&](int c) {
+        const int xso = c * 16 * xcs * 4;
+#pragma unroll
+        for (int j = 0; j < NXS; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xr[j][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, x_voff[j], xso + i * xcs * 4, 0));
+        const int wso = c * w_cstep;
+#pragma unroll
+        for (int j = 0; j < NWS; ++j) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff[j], wso, 0);
+    };
+    auto write_chunk = [&](unsigned char* buf) {
+#pragma unroll
+        for (int j = 0; j < NXS; ++j) {
+            u32x4 h4, l4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v0 = xr[j][2 * i], v1 = xr[j][2 * i + 1];
+                v0 = v0 > 0.f ? v0 : v0 * slope;
+                v1 = v1 > 0.f ? v1 : v1 * slope;
+                const f32x2 v = {v0, v1};
+                const bf16x2 h = __builtin_convertvector(v, bf16x2);
+                const f32x2 r = v - __builtin_convertvector(h, f32x2);
+                const bf16x2 l = __builtin_convertvector(r, bf16x2);
+                h4[i] = __builtin_bit_cast(unsigned, h);
+                l4[i] = __builtin_bit_cast(unsigned, l);
+            }
+            if (masked) {
+                const int l = x_l[j];
+                const bool z = (range_mask && (l < 0 || l >= a.Lin)) || (a.in_mask && ((l & a.in_mask) == a.in_mask));
+                if (z) { h4 = u32x4{0, 0, 0, 0}; l4 = u32x4{0, 0, 0, 0}; }
+            }
+            *reinterpret_cast<u32x4*>(buf + x_lds[j]) = h4;
+            *reinterpret_cast<u32x4*>(buf + xplane + x_lds[j]) = l4;
+        }
+#pragma unroll
+        for (int j = 0; j < NWS; ++j) *reinterpret_cast<u32x4*>(buf + wbase + (tid + NTHR * j) * 16) = wr[j];
+    };
+
+    const int a_off = (wm * WMT + lo) * 32 + hi * 16;  // byte offset of this lane's A row inside one (tap, plane) tile
+    const int b_off = (wl * WLT + lo) * 32 + hi * 16;  // ... of its B position inside a plane
+
+    load_chunk(0);
+    write_chunk(smem3);
+    if (nchunks > 1) load_chunk(1);
+    __syncthreads();
+    for (int s = 0; s < nchunks; ++s) {
+        const unsigned char* cur = smem3 + (s & 1) * bufb;
+        if (s + 1 < nchunks) {
+            write_chunk(smem3 + ((s + 1) & 1) * bufb);
+            if (s + 2 < nchunks) load_chunk(s + 2);
+        }
+        bf16x8 ah[2][RM], al[2][RM], bh[2][RL], bl[2][RL];
+        auto frags = [&](int t, int slot) {
+            const unsigned char* wt = cur + wbase + t * (2 * BM * 32) + a_off;
+            const unsigned char* xt = cur + tap_lds[t] * 32 + b_off;
+#pragma unroll
+            for (int i = 0; i < RM; ++i) {
+                ah[slot][i] = *reinterpret_cast<const bf16x8*>(wt + i * 1024);
+                al[slot][i] = *reinterpret_cast<const bf16x8*>(wt + BM * 32 + i * 1024);
+            }
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                bh[slot][j] = *reinterpret_cast<const bf16x8*>(xt + j * 1024);
+                bl[slot][j] = *reinterpret_cast<const bf16x8*>(xt + xplane + j * 1024);
+            }
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) frags(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const int k = t & 1;
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k][i], bh[k][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k][i], bl[k][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int j = 0; j < RL; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k][i], bh[k][j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff);
+}
+
 // --------------------------------------------------------------------------------------
 // host side: tap tables, tile choice, launch
 // --------------------------------------------------------------------------------------
@@ -659,6 +863,102 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
     return VFX_OK;
 }
 
+
+// ---- bf16x3 launch path (opt-in per launch, vfx_act.math == VFX_MATH_BF16X3).  Returns VFX_ENOTSUP when the
+// geometry is outside what conv_x3_kernel covers; the caller then runs the fp32 kernel.
+#define VFX_ENOTSUP (-100)
+
+template <int BM, int BL, int WGM, int WGL, int NT, bool SEG>
+static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = conv_x3_kernel<BM, BL, WGM, WGL, NT, SEG>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}
+
+template <int BM, int BL, int WGM, int WGL>
+static int launch_x3_tile(const ConvArgs& a, int nt, bool seg, dim3 grid, size_t lds, hipStream_t s) {
+#define VFX_X3(NT_)                                                                                  \
+    if (nt == NT_)                                                                                   \
+        return seg ? launch_x3_one<BM, BL, WGM, WGL, NT_, true>(a, grid, lds, s)                     \
+                   : launch_x3_one<BM, BL, WGM, WGL, NT_, false>(a, grid, lds, s);
+    VFX_X3(1)
+    VFX_X3(2)
+    VFX_X3(3)
+#undef VFX_X3
+    return VFX_ENOTSUP;
+}
+
+static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const PhaseSpec* phs, const void* w3,
+                         hipStream_t stream) {
+    const int Cin = a.Cin, Cout = a.Cout, B = a.B, Lq = a.Lq, Lin = a.Lin;
+    if (!w3 || !vfx_aligned16(w3) || Cin % 16 != 0 || Cout % 64 != 0) return VFX_ENOTSUP;
+    if (a.pad_mode == VFX_PAD_REFLECT || a.pre_act == VFX_PRE_AFFINE_LRELU) return VFX_ENOTSUP;
+    const int nt = phs[0].ntaps;
+    if (nt < 1 || nt > 3) return VFX_ENOTSUP;
+    int span = 0, seg_lo = 0x7fffffff, seg_hi = -0x7fffffff;
+    for (int p = 0; p < nphase; ++p) {
+        if (phs[p].ntaps != nt) return VFX_ENOTSUP;
+        int mn = phs[p].taps[0].off, mx = mn;
+        for (int t = 1; t < nt; ++t) {
+            mn = phs[p].taps[t].off < mn ? phs[p].taps[t].off : mn;
+            mx = phs[p].taps[t].off > mx ? phs[p].taps[t].off : mx;
+        }
+        span = mx - mn > span ? mx - mn : span;
+        seg_lo = mn < seg_lo ? mn : seg_lo;
+        seg_hi = mx > seg_hi ? mx : seg_hi;
+    }
+    const bool seg = span > 120;  // halo tile: (BL + span) positions must fit BL/128 + 1 staging slots
+    int BM, BL;
+    if (Cout % 128 == 0) { BM = 128; BL = 128; }
+    else if (!seg && Lq >= 4096) { BM = 64; BL = 256; }
+    else { BM = 64; BL = 128; }
+    const int segw = seg ? BL : BL + span;
+    ConvTables tb;
+    std::memset(&tb, 0, sizeof(tb));
+    for (int p = 0; p < nphase; ++p) {
+        PhaseTab& T = tb.ph[p];
+        T.ntaps = nt;
+        T.ooff = phs[p].ooff;
+        int mn = phs[p].taps[0].off;
+        for (int t = 1; t < nt; ++t) mn = phs[p].taps[t].off < mn ? phs[p].taps[t].off : mn;
+        T.nseg = seg ? nt : 1;
+        for (int t = 0; t < nt; ++t) {
+            if (seg) { T.seg_org[t] = phs[p].taps[t].off; T.tap_lds[t] = t * segw; }
+            else { T.seg_org[0] = mn; T.tap_lds[t] = phs[p].taps[t].off - mn; }
+            T.tap_w[t] = phs[p].taps[t].slab;
+        }
+    }
+    // every tile must be interior with respect to the guard band (loads inside [-guard, Lin + guard))
+    const int ntiles = (Lq + BL - 1) / BL;
+    const long long g = a.x_guard;
+    if (-(long long)seg_lo > g) return VFX_ENOTSUP;
+    if ((long long)(ntiles - 1) * BL + seg_hi + BL > (long long)Lin + g) return VFX_ENOTSUP;
+    a.tab3 = device_tables(tb);
+    if (!a.tab3) return VFX_EINVAL;
+    a.w3 = w3;
+    a.segw3 = segw;
+    a.xplane3 = (seg ? nt : 1) * segw * 32;
+    a.buf3 = 2 * a.xplane3 + nt * 2 * BM * 32;
+    a.tile_lo = 0;
+    a.tile_hi = ntiles;
+    const size_t lds = 2ull * a.buf3;
+    if (lds > 160 * 1024) return VFX_ENOTSUP;
+    const dim3 grid(ntiles, nphase * Cout / BM, B);
+    g_last_tile = BM * 100000 + BL * 100 + 16;
+    (void)x;
+    if (BM == 128) return launch_x3_tile<128, 128, 2, 2>(a, nt, seg, grid, lds, stream);
+    if (BL == 256) return launch_x3_tile<64, 256, 1, 4>(a, nt, seg, grid, lds, stream);
+    return launch_x3_tile<64, 128, 1, 4>(a, nt, seg, grid, lds, stream);
+}
+
 static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, const vfx_tensor* res,
                        const vfx_tensor* y, int B, int Cin, int Cout, int Lin, int Lq, int Lout,
                        int nphase, const PhaseSpec* phs, int q_shift, int q_mask, int o_rs, int o_cs,
@@ -698,6 +998,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     int maxnt = 0;
     for (int p = 0; p < nphase; ++p) maxnt = phs[p].ntaps > maxnt ? phs[p].ntaps : maxnt;
     if (maxnt < 1 || maxnt > VFX_MAXT) return VFX_EINVAL;
+    if (act && act->math == VFX_MATH_BF16X3) {
+        const int rc3 = try_launch_x3(a, x, nphase, phs, act->w_x3, stream);
+        if (rc3 != VFX_ENOTSUP) return rc3;
+    }
     // tile choice: maximise (tile efficiency) x (tail efficiency along L) x (wave quantisation)
     int best = -1;
     float best_score = -1.f;

@@ -47,10 +47,11 @@ def _dev(t, device):
 class VocoderEngine:
     """TFGAN-style 44.1 kHz generator: cond (B,128,T') -> wav (B,1,441*T')."""
 
-    def __init__(self, state, device="cuda"):
+    def __init__(self, state, device="cuda", math="f32"):
         sd = weights.normalise_vocoder_keys(state)
         weights.check_state(sd, weights.vocoder_manifest(), "vocoder")
         self.device = device
+        self.set_math(math)
 
         def wn(prefix):
             return weights.fold_weight_norm(sd[prefix + ".parametrizations.weight.original0"].float(),
@@ -81,6 +82,24 @@ class VocoderEngine:
         self.act_last_snake = ops.Act(post=POST_LRELU_SNAKE, post_slope=0.2)
         self.act_last = ops.Act(post=POST_LRELU, post_slope=0.2)
 
+    def set_math(self, math):
+        """"f32" (default: exact fp32 MFMA) or "bf16x3" (opt-in VFX_MATH_BF16X3: split-bf16 products with fp32
+        accumulation; bf16 weight planes are packed lazily, once per layer)."""
+        if math not in ("f32", "bf16x3"):
+            raise ValueError("math must be 'f32' or 'bf16x3'")
+        self.math = math
+        if not hasattr(self, "_w3"):
+            self._w3 = {}
+
+    def _x3(self, w):
+        if self.math != "bf16x3":
+            return None
+        key = w.data_ptr()
+        if key not in self._w3:
+            p = packing.pack_x3(w.cpu())
+            self._w3[key] = None if p is None else p.to(w.device)
+        return self._w3[key]
+
     def forward_cond(self, cond, Tc, stages=None):
         """cond: device (B,128,>=Tc) channel-major.  Returns (wav buffer (B,1,Lp), L = 441*Tc)."""
         B = cond.shape[0]
@@ -90,7 +109,7 @@ class VocoderEngine:
         x = cond
         for i, (w, bias) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
-            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu)
+            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w))
             x = y
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
@@ -105,14 +124,14 @@ class VocoderEngine:
             c //= 2
             xs = _rows(B, c, Lo, G_DIL, dev)
             ys = _rows(B, c, Lo, G_TILE, dev)
-            ops.convtr1d(h, upw[0], upw[1], xs, L, s, self.act_none)
+            ops.convtr1d(h, upw[0], upw[1], xs, L, s, self.act_none, w3=self._x3(upw[0]))
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
             for i, (w1, b1, w2, b2) in enumerate(layers):
-                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1)
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1))
                 last = i == len(layers) - 1
                 act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
-                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs)  # residual updated in place
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2))  # residual updated in place
             h = xs
             L = Lo
             del ys

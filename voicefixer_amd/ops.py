@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import (vfx_tensor, vfx_act, check, PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU, POST_NONE,
                    POST_LRELU, POST_ELU, POST_TANH, POST_SIGMOID, POST_LRELU_SNAKE, PAD_ZERO,
-                   PAD_REFLECT)
+                   PAD_REFLECT, MATH_F32, MATH_BF16X3)
 
 
 def _stream():
@@ -81,18 +81,29 @@ class Act:
 
 
 _NOACT = None
+_X3ACTS = {}
 
 
-def _act(a):
+def _act(a, w3=None):
+    """vfx_act* for a launch; ``w3`` (packing.pack_x3 planes on the device) opts the launch into
+    VFX_MATH_BF16X3 (the library falls back to fp32 for geometries its bf16x3 kernel does not cover)."""
     global _NOACT
     if a is None:
         if _NOACT is None:
             _NOACT = Act()
         a = _NOACT
-    return C.byref(a.c)
+    if w3 is None:
+        return C.byref(a.c)
+    key = (id(a), w3.data_ptr())
+    ent = _X3ACTS.get(key)
+    if ent is None:
+        c = vfx_act(a.c.pre_act, a.c.pre_slope, a.c.pre_scale, a.c.pre_shift, a.c.post_act, a.c.post_slope,
+                    MATH_BF16X3, w3.data_ptr())
+        ent = _X3ACTS[key] = (c, a, w3)  # keep the owners alive with the struct
+    return C.byref(ent[0])
 
 
-def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None):
+def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None):
     """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout]."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
@@ -102,24 +113,24 @@ def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=Non
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act), _stream())
+                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3), _stream())
     check(rc, "vfx_conv1d_f32")
     _prof_end(e0, B * L * cin * cout * k)
 
 
-def convtr1d(x, w, bias, y, Lin, stride, act=None):
+def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None):
     _need_cuda(x, w, y, bias)
     B, cin = x.shape[0], x.shape[1]
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
     e0 = _prof_begin()
     rc = _lib.lib().vfx_convtr1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(yd), B, cin, cout, Lin, stride,
-                                     _act(act), _stream())
+                                     _act(act, w3), _stream())
     check(rc, "vfx_convtr1d_f32")
     _prof_end(e0, B * Lin * cin * cout * 2 * stride)
 
 
-def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None):
+def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3=None):
     """x (B,Cin,H*P) pitch map -> y (B,Cout,H*P)."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
@@ -129,19 +140,19 @@ def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None):
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv2d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act), _stream())
+                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act, w3), _stream())
     check(rc, "vfx_conv2d_f32")
     _prof_end(e0, B * H * ((1 << pitch_log2) - 1) * cin * cout * ksize * ksize)
 
 
-def convtr2d_3x3s2(x, w, y, h, in_pitch_log2, act=None):
+def convtr2d_3x3s2(x, w, y, h, in_pitch_log2, act=None, w3=None):
     _need_cuda(x, w, y)
     B, cin = x.shape[0], x.shape[1]
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
     e0 = _prof_begin()
     rc = _lib.lib().vfx_convtr2d_3x3s2_f32(C.byref(xd), _ptr(w), C.byref(yd), B, cin, cout, h, in_pitch_log2,
-                                           _act(act), _stream())
+                                           _act(act, w3), _stream())
     check(rc, "vfx_convtr2d_3x3s2_f32")
     _prof_end(e0, B * h * ((1 << in_pitch_log2) - 1) * cin * cout * 9)
 
