@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (no 2:1 sparsity), same guide
 SR = 44100
 
 
@@ -66,6 +67,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue consecutive steps (batches) round-robin on this many HIP streams")
+    ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32",
+                    help="contraction arithmetic: exact fp32 MFMA (default, the headline) or the opt-in split-bf16 "
+                         "products with fp32 accumulation (DESIGN.md 3.4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -84,7 +88,7 @@ def main():
     from voicefixer_amd import engine, ops, weights
 
     n = int(round(args.seconds * SR))
-    pipe = engine.Pipeline(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321), dev)
+    pipe = engine.Pipeline(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321), dev, args.math)
     wav = synth_batch(args.batch, n, 1000 + rank, dev)
 
     def barrier():
@@ -147,10 +151,16 @@ def main():
         for kname, rec in json.load(open(tfile))["kernels"].items():
             if want in kname and ", %d, true>" % (tile % 100) in kname:
                 traffic = rec["hbm_bytes_per_launch"]
+    x3_dom = args.math == "bf16x3" and tile % 100 == 16
+    # bf16x3 instance: three bf16 MFMA products per algorithmic product -> peak = dense bf16 peak / 3
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3_dom else FP32_MFMA_PEAK_TFLOPS
+    if x3_dom:
+        traffic = None
     roofline = {
-        "bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-        "kernel": "conv_taps_kernel<BM=%d,BL=%d,KC=%d,FAST>" % (tile // 100000, tile // 100 % 1000, tile % 100),
+        "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+        "frac": round(achieved / peak, 4), "traffic": traffic,
+        "kernel": ("conv_x3_kernel<BM=%d,BL=%d,KC=%d>" if x3_dom else "conv_taps_kernel<BM=%d,BL=%d,KC=%d,FAST>")
+                  % (tile // 100000, tile // 100 % 1000, tile % 100),
         "launches_per_step": launches // args.steps,
         "avg_launch_ms": round(secs / launches * 1e3, 4),
         "algorithmic_gflop_per_launch": round(2.0 * macs / launches / 1e9, 3),
@@ -171,7 +181,7 @@ def main():
         "metric": "seconds-of-44.1kHz-audio restored per wall-second",
         "value": round(value, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
         "config": {"workload": "batched folder restore (BASELINE configs[2]): one batch of %d x %.0f s 44.1 kHz "
                                "utterances per step, VoiceFixer.restore mode 0, seeded random weights"
                                % (args.batch, args.seconds),

@@ -76,7 +76,7 @@ typedef struct {
     float post_slope;
     int math;               /* VFX_MATH_* */
     const void* w_x3;       /* VFX_MATH_BF16X3: the packed weights as bf16 (hi, lo) planes, layout
-                               [slab][Cin/16][plane][Cout][16] (voicefixer_amd/packing.py::pack_x3) */
+                               [slab][Cin/16][plane][k-half][Cout][8] (voicefixer_amd/packing.py::pack_x3) */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0

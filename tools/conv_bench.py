@@ -20,8 +20,10 @@ SHAPES = {
     "res4_d27": ("c1", 64, 64, 443646, 3, 27),
     "res4_d2187": ("c1", 64, 64, 443646, 3, 2187),
     "res3_d1": ("c1", 128, 128, 147882, 3, 1),
+    "res3_d9": ("c1", 128, 128, 147882, 3, 9),
     "res2_d1": ("c1", 256, 256, 49294, 3, 1),
     "res2_d243": ("c1", 256, 256, 49294, 3, 243),
+    "res2_d27": ("c1", 256, 256, 49294, 3, 27),
     "res1_d1": ("c1", 512, 512, 7042, 3, 1),
     "res1_d729": ("c1", 512, 512, 7042, 3, 729),
     "pre_k7": ("c1r", 512, 1024, 1006, 7, 1),

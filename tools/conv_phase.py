@@ -11,17 +11,20 @@ h = _lib.lib()
 h.vfx_debug_read.restype = C.c_int
 buf = (C.c_ulonglong * 8)()
 B = 8
-for name in sys.argv[1:]:
+X3 = "--x3" in sys.argv
+for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
     kind, cin, cout, L, k, dil = cb.SHAPES[name]
     g = torch.Generator().manual_seed(1)
     Lp = (L + 3) // 4 * 4
-    x = torch.randn((B, cin, Lp), device="cuda"); y = torch.empty((B, cout, Lp), device="cuda")
-    w = packing.pack_conv1d(torch.randn((cout, cin, k), generator=g) * (cin * k) ** -0.5).cuda()
+    x = ops.guarded(B, cin, L, dil + 264, "cuda"); x.normal_(); y = torch.empty((B, cout, Lp), device="cuda")
+    wp = packing.pack_conv1d(torch.randn((cout, cin, k), generator=g) * (cin * k) ** -0.5)
+    w = wp.cuda()
+    w3 = packing.pack_x3(wp).cuda() if X3 else None
     bias = torch.zeros(cout, device="cuda")
     act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
-    ops.conv1d(x, w, bias, y, L, k, dil, 0, act); torch.cuda.synchronize()
+    ops.conv1d(x, w, bias, y, L, k, dil, 0, act, w3=w3); torch.cuda.synchronize()
     h.vfx_debug_read(buf, 1)
-    ops.conv1d(x, w, bias, y, L, k, dil, 0, act); torch.cuda.synchronize()
+    ops.conv1d(x, w, bias, y, L, k, dil, 0, act, w3=w3); torch.cuda.synchronize()
     h.vfx_debug_read(buf, 1)
     n, steps = buf[6], buf[7]
     per = lambda v: v / max(steps, 1)

@@ -83,11 +83,12 @@ struct ConvArgs {
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
     int x_guard;            // readable elements before every input row (vfx_tensor.guard)
     // ---- bf16x3 instance (conv_x3_kernel) only
-    const void* w3;         // weights as bf16 hi/lo planes: [slab][Cin/16][plane][Cout][16]
+    const void* w3;         // weights as bf16 hi/lo planes: [slab][Cin/16][plane][k-half][Cout][8]
     const ConvTables* tab3; // tap tables in POSITIONS (no 4-alignment: the x3 staging moves single floats)
     int segw3;              // positions per staged segment
     int xplane3;            // bytes between the hi and the lo plane of the activation tile
     int buf3;               // bytes per LDS buffer (activation planes + weight tile)
+    int bl3;                // output positions per tile (< BL when the halo is staged inside the BL columns)
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -260,10 +261,28 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
         }
 }
 
-// ---- epilogue of one tile: C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// ---- accumulators start at the bias (C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+// the loads overlap the first K-chunk; in the epilogue they were 16 exposed load->use round trips per wave
+template <int RM, int RL>
+__device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[RM][RL], const float* __restrict__ bias, int nbase) {
+#pragma unroll
+    for (int i = 0; i < RM; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bq = bias ? *reinterpret_cast<const float4*>(bias + nbase + i * 32 + 8 * g)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < RL; ++j) {
+                acc[i][j][4 * g + 0] = bq.x; acc[i][j][4 * g + 1] = bq.y;
+                acc[i][j][4 * g + 2] = bq.z; acc[i][j][4 * g + 3] = bq.w;
+            }
+        }
+}
+
+// ---- epilogue of one tile (bias is already in the accumulators)
 template <int BM, int BL, int WGM, int WGL>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BL / WGL / 32], int q0,
-                                              int m0, int b, int wm, int wl, int lo, int hi, int ooff) {
+                                              int m0, int b, int wm, int wl, int lo, int hi, int ooff, int qend) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
     float* __restrict__ yb = a.y + (long long)b * a.y_bs;
     const float* __restrict__ rb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
@@ -278,7 +297,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         for (int j = 0; j < RL; ++j) {
             const int q = q0 + wl * WLT + j * 32 + lo;
             const int out = (q >> a.q_shift) * a.o_rs + (q & a.q_mask) * a.o_cs + ooff;
-            const bool ok = q < a.Lq && out >= 0 && out < a.Lout;
+            const bool ok = q < qend && out >= 0 && out < a.Lout;
             const bool zero = a.out_mask && ((out & a.out_mask) == a.out_mask);
 #pragma unroll
             for (int i = 0; i < RM; ++i) {
@@ -288,10 +307,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
                     const int ro = n0 * rcs + out * rls;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
-                        const float4 bq = a.bias ? *reinterpret_cast<const float4*>(a.bias + n0 + 8 * g)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                        float v0 = acc[i][j][4 * g + 0] + bq.x, v1 = acc[i][j][4 * g + 1] + bq.y;
-                        float v2 = acc[i][j][4 * g + 2] + bq.z, v3 = acc[i][j][4 * g + 3] + bq.w;
+                        float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1];
+                        float v2 = acc[i][j][4 * g + 2], v3 = acc[i][j][4 * g + 3];
                         if (rb) {
                             v0 += rb[ro + (8 * g + 0) * rcs];
                             v1 += rb[ro + (8 * g + 1) * rcs];
@@ -315,7 +332,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
         for (int j = 0; j < RL; ++j) {
             const int q = q0 + wl * WLT + j * 32 + lo;
             const int out = (q >> a.q_shift) * a.o_rs + (q & a.q_mask) * a.o_cs + ooff;
-            const bool ok = q < a.Lq && out >= 0 && out < a.Lout;
+            const bool ok = q < qend && out >= 0 && out < a.Lout;
             const bool zero = a.out_mask && ((out & a.out_mask) == a.out_mask);
 #pragma unroll
             for (int i = 0; i < RM; ++i) {
@@ -326,7 +343,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
                     const int n = nbase + i * 32 + (r & 3) + 8 * (r >> 2);
                     if (ok) {
                         float v = acc[i][j][r];
-                        if (a.bias) v += a.bias[n];
                         if (rb) v += rb[(long long)n * a.r_cs + (long long)out * a.r_ls];
                         v = vfx_post(v, a.post_act, a.post_slope);
                         if (zero) v = 0.f;
@@ -412,12 +428,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     }
 
     f32x16 acc[RM][RL];
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RL; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
 
     const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
     const int a_col = wm * WMT + lo;  // column into the weight tile row
@@ -529,7 +540,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 #if VFX_ABL & 8
     const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
-    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff);
+    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff, a.Lq);
 #if VFX_ABL & 8
     if (tid == 0 && FAST) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -549,22 +560,26 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 // Measured end-to-end waveform error vs the fp32 path: 2e-6 RMS, the same size as the difference
 // between two fp32 summation orders.  Opt-in (vfx_act.math).
 //
-// LDS image per K-chunk of 16 channels: activations as [plane][position][16 ch] bf16 (32 B per position
-// and plane: one ds_read_b128 per lane yields the 8 consecutive k of an MFMA B operand, a wave reads 1 KB
-// contiguous), weights as [tap][plane][row][16 k] in exactly the global packing order (straight copy).
-// A staging unit is (position, 8-channel half): 8 single-float buffer loads that differ only in their
-// scalar offset, activation + split in registers, two 16-byte LDS writes.
+// LDS image per K-chunk of 16 channels: activations as [plane][k-half][position][8 ch] bf16 (one ds_read_b128
+// per lane yields the 8 consecutive k of an MFMA B operand; the 32 lanes of a k-half read 512 contiguous
+// bytes: no bank conflicts), weights as [tap][plane][k-half][row][8 k] in exactly the global packing order
+// (straight copy).  A staging unit is (position, 8-channel half): 8 single-float buffer loads that differ
+// only in their scalar offset, activation + split in registers, two 16-byte LDS writes.
 // --------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int BM, int BL, int WGM, int WGL, int NT, bool SEG>
+// MODE 0: halo tile staged in exactly BL columns (tile = BL - span output positions: no extra staging slot,
+//         for small spans); 1: halo tile of BL + span columns (one extra slot); 2: one BL-column segment per tap.
+template <int BM, int BL, int WGM, int WGL, int NT, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
     constexpr int NTHR = 256;
-    constexpr int NXS = SEG ? (NT * BL * 2) / NTHR : (BL * 2) / NTHR + 1;  // (position, k-half) units per thread
-    constexpr int NWS = (NT * BM * 4) / NTHR;                             // 16-byte weight vectors per thread
+    constexpr bool SEG = MODE == 2;
+    constexpr int XDEPTH = SEG ? 1 : 2;  // activation prefetch distance in steps (= register sets)
+    constexpr int NXS = SEG ? (NT * BL * 2) / NTHR : (BL * 2) / NTHR + MODE;  // (position, k-half) units per thread
+    constexpr int NWS = (NT * BM * 4) / NTHR;                                 // 16-byte weight vectors per thread
     static_assert(WGM * WGL == 4 && (NT * BM * 4) % NTHR == 0 && (BL * 2) % NTHR == 0, "tile/thread mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
@@ -572,7 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     const int lo = lane & 31, hi = lane >> 5;
     const int wm = wave / WGL, wl = wave % WGL;
     const int tile = blockIdx.x + a.tile_lo;
-    const int q0 = tile * BL;
+    const int q0 = tile * a.bl3;
     const int m0g = blockIdx.y * BM;
     const int ph = m0g / a.Cout;
     const int m0 = m0g - ph * a.Cout;
@@ -583,24 +598,27 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     for (int t = 0; t < NT; ++t) tap_lds[t] = __builtin_amdgcn_readfirstlane(pt->tap_lds[t]);
     const int segw = a.segw3;
     const int nseg = SEG ? NT : 1;
-    const int xunits = nseg * segw * 2;
+    const int npos = nseg * segw;
+    const int xunits = npos * 2;
     const int xcs = (int)a.x_cs;
     const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
     const int nchunks = a.Cin >> 4;
 
-    // ---- per-thread staging slots, fixed for the whole K loop
+    // ---- per-thread staging slots, fixed for the whole K loop.  Units are enumerated k-half major so that
+    // consecutive lanes hold consecutive positions: coalesced loads, contiguous (conflict-free) LDS writes.
     int x_voff[NXS];   // byte offset of (channel 8*kh, position) from the row base; channel i of the half adds a scalar
     int x_l[NXS];      // global position (range / pad-column masks)
     int x_lds[NXS];    // byte offset of the unit's hi vector in the activation tile
-    const float inv_sw = 1.0f / (float)(segw * 2);
+    const float inv_sw = 1.0f / (float)segw;
 #pragma unroll
     for (int j = 0; j < NXS; ++j) {
         int u = tid + NTHR * j;
         u = u < xunits ? u : xunits - 1;  // clamped duplicates rewrite the same value
-        const int s = SEG ? fast_div(u, segw * 2, inv_sw) : 0;
-        const int rem = u - s * segw * 2;
-        const int pos = rem >> 1, kh = rem & 1;
-        const int l = q0 + pt->seg_org[s] + pos;
+        const int kh = u >= npos ? 1 : 0;
+        const int p = u - kh * npos;
+        const int sg = SEG ? fast_div(p, segw, inv_sw) : 0;
+        const int pos = p - sg * segw;
+        const int l = q0 + pt->seg_org[sg] + pos;
         x_l[j] = l;
         x_voff[j] = (kh * 8 * xcs + l + a.x_guard) * 4;
         x_lds[j] = u * 16;
@@ -608,28 +626,27 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     int w_voff[NWS];
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
-        const int v = tid + NTHR * j;
+        const int v = tid + NTHR * j;       // LDS order [tap][plane][k-half][row], 16 bytes each
         const int t = v / (BM * 4);
-        const int rem = v - t * (BM * 4);
-        const int plane = rem / (BM * 2);
-        const int r2 = rem - plane * (BM * 2);
-        w_voff[j] = (((pt->tap_w[t] * nchunks * 2 + plane) * a.Cout + m0) * 32) + r2 * 16;
+        const int rem = v - t * (BM * 4);   // = (plane*2 + kh)*BM + row
+        const int pk = rem / BM;
+        const int row = rem - pk * BM;
+        w_voff[j] = (((pt->tap_w[t] * nchunks * 4 + pk) * a.Cout) + m0 + row) * 16;
     }
-    const int w_cstep = 2 * a.Cout * 32;  // bytes per 16-channel chunk in the packed weights
+    const int w_cstep = 4 * a.Cout * 16;  // bytes per 16-channel chunk in the packed weights
 
     f32x16 acc[RM][RL];
-#pragma unroll
-    for (int i = 0; i < RM; ++i)
-#pragma unroll
-        for (int j = 0; j < RL; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
 
     const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
-    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+    const __amdgpu_buffer_rsrc_t xrsrc_real = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(xb) - a.x_guard, (short)0, 0x7fffffff, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrsrc =
+    const __amdgpu_buffer_rsrc_t wrsrc_real =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), (short)0, 0x7fffffff, 0x00020000);
+    // loads of chunks past the end stay in the instruction stream (see the loop) but go through a zero-length
+    // buffer resource: they return 0 without touching memory
+    const __amdgpu_buffer_rsrc_t nullrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, 0, 0x00020000);
 
     bool range_mask = false;
 #pragma unroll
@@ -642,26 +659,37 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     const int xplane = a.xplane3, bufb = a.buf3;
     const int wbase = 2 * xplane;  // weight tile follows the two activation planes
 
-    float xr[NXS][8];
+    // Prefetch distances: activations (HBM latency) two steps -- two register sets, the loads of chunk s+3 are
+    // issued in step s and consumed in step s+2; weights (L2 hits) one step -- one register set, loaded BEFORE the
+    // activations of the same step so that waiting for them (in-order vmcnt) never waits for younger activation
+    // loads.  Per-tap segments (MODE 2) need three slots per set and keep one set.
+    const int xcs4 = __builtin_amdgcn_readfirstlane(xcs * 4);
+    float xr[XDEPTH][NXS][8];
     u32x4 wr[NWS];
-    auto load_chunk = [&](int c) {
-        const int xso = c * 16 * xcs * 4;
+    auto load_x = [&](int c, int set) {
+        const __amdgpu_buffer_rsrc_t xrsrc = c < nchunks ? xrsrc_real : nullrsrc;
+        const int xso = __builtin_amdgcn_readfirstlane(c * 16 * xcs * 4);
 #pragma unroll
-        for (int j = 0; j < NXS; ++j)
+        for (int i = 0; i < 8; ++i) {
+            const int so = xso + i * xcs4;  // scalar: one s_add per channel row
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
-                xr[j][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, x_voff[j], xso + i * xcs * 4, 0));
-        const int wso = c * w_cstep;
+            for (int j = 0; j < NXS; ++j)
+                xr[set][j][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, x_voff[j], so, 0));
+        }
+    };
+    auto load_w = [&](int c) {
+        const __amdgpu_buffer_rsrc_t wrsrc = c < nchunks ? wrsrc_real : nullrsrc;
+        const int wso = __builtin_amdgcn_readfirstlane(c * w_cstep);
 #pragma unroll
         for (int j = 0; j < NWS; ++j) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff[j], wso, 0);
     };
-    auto write_chunk = [&](unsigned char* buf) {
+    auto write_chunk = [&](unsigned char* buf, int set) {
 #pragma unroll
         for (int j = 0; j < NXS; ++j) {
             u32x4 h4, l4;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                float v0 = xr[j][2 * i], v1 = xr[j][2 * i + 1];
+                float v0 = xr[set][j][2 * i], v1 = xr[set][j][2 * i + 1];
                 v0 = v0 > 0.f ? v0 : v0 * slope;
                 v1 = v1 > 0.f ? v1 : v1 * slope;
                 const f32x2 v = {v0, v1};
@@ -678,64 +706,140 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             }
             *reinterpret_cast<u32x4*>(buf + x_lds[j]) = h4;
             *reinterpret_cast<u32x4*>(buf + xplane + x_lds[j]) = l4;
+            __builtin_amdgcn_sched_barrier(0);  // one slot's conversion temporaries at a time
         }
 #pragma unroll
         for (int j = 0; j < NWS; ++j) *reinterpret_cast<u32x4*>(buf + wbase + (tid + NTHR * j) * 16) = wr[j];
+        __builtin_amdgcn_sched_barrier(0);
     };
 
-    const int a_off = (wm * WMT + lo) * 32 + hi * 16;  // byte offset of this lane's A row inside one (tap, plane) tile
-    const int b_off = (wl * WLT + lo) * 32 + hi * 16;  // ... of its B position inside a plane
+    // fragment addresses: a lane's 8 consecutive k sit in one 16-byte granule; granules of one k-half are
+    // contiguous over rows / positions, so every 16-lane group of a ds_read_b128 covers 256 contiguous bytes
+    const int a_off = (hi * BM + wm * WMT + lo) * 16;    // inside one (tap, plane) weight tile of BM*32 bytes
+    const int b_off = (hi * npos + wl * WLT + lo) * 16;  // inside one activation plane
 
-    load_chunk(0);
-    write_chunk(smem3);
-    if (nchunks > 1) load_chunk(1);
-    __syncthreads();
-    for (int s = 0; s < nchunks; ++s) {
-        const unsigned char* cur = smem3 + (s & 1) * bufb;
-        if (s + 1 < nchunks) {
-            write_chunk(smem3 + ((s + 1) & 1) * bufb);
-            if (s + 2 < nchunks) load_chunk(s + 2);
-        }
-        bf16x8 ah[2][RM], al[2][RM], bh[2][RL], bl[2][RL];
-        auto frags = [&](int t, int slot) {
+    // one tap's fragments live at a time: the other wave of the SIMD covers the LDS latency (a second fragment
+    // set, i.e. reading tap t+1 during tap t's MFMAs, was measured: no gain)
+    auto mfma_chunk = [&](const unsigned char* cur) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bf16x8 ah[RM], al[RM], bh[RL], bl[RL];
             const unsigned char* wt = cur + wbase + t * (2 * BM * 32) + a_off;
-            const unsigned char* xt = cur + tap_lds[t] * 32 + b_off;
+            const unsigned char* xt = cur + tap_lds[t] * 16 + b_off;
 #pragma unroll
             for (int i = 0; i < RM; ++i) {
-                ah[slot][i] = *reinterpret_cast<const bf16x8*>(wt + i * 1024);
-                al[slot][i] = *reinterpret_cast<const bf16x8*>(wt + BM * 32 + i * 1024);
+                ah[i] = *reinterpret_cast<const bf16x8*>(wt + i * 512);
+                al[i] = *reinterpret_cast<const bf16x8*>(wt + BM * 32 + i * 512);
             }
 #pragma unroll
             for (int j = 0; j < RL; ++j) {
-                bh[slot][j] = *reinterpret_cast<const bf16x8*>(xt + j * 1024);
-                bl[slot][j] = *reinterpret_cast<const bf16x8*>(xt + xplane + j * 1024);
+                bh[j] = *reinterpret_cast<const bf16x8*>(xt + j * 512);
+                bl[j] = *reinterpret_cast<const bf16x8*>(xt + xplane + j * 512);
             }
-        };
-        frags(0, 0);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t + 1 < NT) frags(t + 1, (t + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            const int k = t & 1;
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
                 for (int j = 0; j < RL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[k][i], bh[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
                 for (int j = 0; j < RL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k][i], bl[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < RM; ++i)
 #pragma unroll
                 for (int j = 0; j < RL; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[k][i], bh[k][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    // nchunks is even (host: Cin % 32 == 0).  Every load below is unconditional: a branch around a load makes
+    // the compiler merge "in flight" with "not in flight" at the join and wait for everything (vmcnt(0)), which
+    // would undo the prefetch distance.  Chunks past the end are read through the zero-length resource.
+    load_w(0);
+    load_x(0, 0);
+    write_chunk(smem3, 0);
+    load_w(1);
+    load_x(1, 0);
+    if constexpr (XDEPTH == 2) load_x(2, 1);
+    __syncthreads();
+#if VFX_ABL & 8
+    unsigned long long d_write = 0, d_load = 0, d_mfma = 0, d_bar = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
+    // step s computes chunk s from LDS buffer s&1; activation set (s&1 or 0) and the weight set hold chunk s+1.
+    // The last pair runs the same body.  (A peeled tail made LLVM rotate the loop around the common prefix,
+    // which cost 64 accumulator moves per iteration and ~40 spilled registers; nounroll keeps it from peeling.)
+#pragma nounroll
+    for (int s = 0; s < nchunks; s += 2) {
+        DBG_T(t0);
+#if !(VFX_ABL & 1)
+        write_chunk(smem3 + bufb, 0);
+#if VFX_ABL & 8
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        DBG_T(t1);
+        load_w(s + 2);
+        load_x(s + (XDEPTH == 2 ? 3 : 2), 0);
+#else
+        DBG_T(t1);
+#endif
+        DBG_T(t2);
+#if !(VFX_ABL & 4)
+        mfma_chunk(smem3);
+#endif
+#if VFX_ABL & 8
+        asm volatile("s_nop 0" ::: "memory");
+#endif
+        DBG_T(t3);
+#if !(VFX_ABL & 2)
         __syncthreads();
+#endif
+        DBG_T(t4);
+#if !(VFX_ABL & 1)
+        if (s + 2 < nchunks) write_chunk(smem3, XDEPTH - 1);  // (no load inside the branch)
+#if VFX_ABL & 8
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        DBG_T(t5);
+        load_w(s + 3);
+        load_x(s + (XDEPTH == 2 ? 4 : 3), XDEPTH - 1);
+#else
+        DBG_T(t5);
+#endif
+        DBG_T(t6);
+#if !(VFX_ABL & 4)
+        mfma_chunk(smem3 + bufb);
+#endif
+#if VFX_ABL & 8
+        asm volatile("s_nop 0" ::: "memory");
+#endif
+        DBG_T(t7);
+#if !(VFX_ABL & 2)
+        __syncthreads();
+#endif
+        DBG_T(t8);
+#if VFX_ABL & 8
+        d_write += (t1 - t0) + (t5 - t4); d_load += (t2 - t1) + (t6 - t5);
+        d_mfma += (t3 - t2) + (t7 - t6); d_bar += (t4 - t3) + (t8 - t7);
+#endif
     }
-    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff);
+#if VFX_ABL & 8
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
+    const int qe = q0 + a.bl3;
+    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff, qe < a.Lq ? qe : a.Lq);
+#if VFX_ABL & 8
+    if (tid == 0) {
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        atomicAdd(&g_dbg[0], d_write); atomicAdd(&g_dbg[1], d_load); atomicAdd(&g_dbg[2], d_mfma);
+        atomicAdd(&g_dbg[3], d_bar); atomicAdd(&g_dbg[4], t_loop - t_start); atomicAdd(&g_dbg[5], t_end - t_loop);
+        atomicAdd(&g_dbg[6], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)nchunks);
+    }
+#endif
 }
 
 // --------------------------------------------------------------------------------------
@@ -868,10 +972,10 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
 // geometry is outside what conv_x3_kernel covers; the caller then runs the fp32 kernel.
 #define VFX_ENOTSUP (-100)
 
-template <int BM, int BL, int WGM, int WGL, int NT, bool SEG>
+template <int BM, int BL, int WGM, int WGL, int NT, int MODE>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_x3_kernel<BM, BL, WGM, WGL, NT, SEG>;
+    auto kern = conv_x3_kernel<BM, BL, WGM, WGL, NT, MODE>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -884,11 +988,12 @@ static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s
 }
 
 template <int BM, int BL, int WGM, int WGL>
-static int launch_x3_tile(const ConvArgs& a, int nt, bool seg, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_x3_tile(const ConvArgs& a, int nt, int mode, dim3 grid, size_t lds, hipStream_t s) {
 #define VFX_X3(NT_)                                                                                  \
     if (nt == NT_)                                                                                   \
-        return seg ? launch_x3_one<BM, BL, WGM, WGL, NT_, true>(a, grid, lds, s)                     \
-                   : launch_x3_one<BM, BL, WGM, WGL, NT_, false>(a, grid, lds, s);
+        return mode == 2   ? launch_x3_one<BM, BL, WGM, WGL, NT_, 2>(a, grid, lds, s)                \
+               : mode == 1 ? launch_x3_one<BM, BL, WGM, WGL, NT_, 1>(a, grid, lds, s)                \
+                           : launch_x3_one<BM, BL, WGM, WGL, NT_, 0>(a, grid, lds, s);
     VFX_X3(1)
     VFX_X3(2)
     VFX_X3(3)
@@ -899,7 +1004,7 @@ static int launch_x3_tile(const ConvArgs& a, int nt, bool seg, dim3 grid, size_t
 static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const PhaseSpec* phs, const void* w3,
                          hipStream_t stream) {
     const int Cin = a.Cin, Cout = a.Cout, B = a.B, Lq = a.Lq, Lin = a.Lin;
-    if (!w3 || !vfx_aligned16(w3) || Cin % 16 != 0 || Cout % 64 != 0) return VFX_ENOTSUP;
+    if (!w3 || !vfx_aligned16(w3) || Cin % 32 != 0 || Cout % 64 != 0) return VFX_ENOTSUP;
     if (a.pad_mode == VFX_PAD_REFLECT || a.pre_act == VFX_PRE_AFFINE_LRELU) return VFX_ENOTSUP;
     const int nt = phs[0].ntaps;
     if (nt < 1 || nt > 3) return VFX_ENOTSUP;
@@ -915,12 +1020,16 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
         seg_lo = mn < seg_lo ? mn : seg_lo;
         seg_hi = mx > seg_hi ? mx : seg_hi;
     }
-    const bool seg = span > 120;  // halo tile: (BL + span) positions must fit BL/128 + 1 staging slots
+    // staging mode: 0 = halo inside the BL staged columns (tile of BL - span outputs, small spans),
+    // 1 = BL + span columns (one more staging slot), 2 = one segment per tap (large dilations)
+    const int mode = span <= 8 ? 0 : (span <= 120 ? 1 : 2);
+    const bool seg = mode == 2;
     int BM, BL;
     if (Cout % 128 == 0) { BM = 128; BL = 128; }
     else if (!seg && Lq >= 4096) { BM = 64; BL = 256; }
     else { BM = 64; BL = 128; }
-    const int segw = seg ? BL : BL + span;
+    const int segw = mode == 1 ? BL + span : BL;
+    const int bl_eff = mode == 0 ? BL - span : BL;
     ConvTables tb;
     std::memset(&tb, 0, sizeof(tb));
     for (int p = 0; p < nphase; ++p) {
@@ -937,14 +1046,15 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
         }
     }
     // every tile must be interior with respect to the guard band (loads inside [-guard, Lin + guard))
-    const int ntiles = (Lq + BL - 1) / BL;
+    const int ntiles = (Lq + bl_eff - 1) / bl_eff;
     const long long g = a.x_guard;
     if (-(long long)seg_lo > g) return VFX_ENOTSUP;
-    if ((long long)(ntiles - 1) * BL + seg_hi + BL > (long long)Lin + g) return VFX_ENOTSUP;
+    if ((long long)(ntiles - 1) * bl_eff + seg_hi + BL > (long long)Lin + g) return VFX_ENOTSUP;
     a.tab3 = device_tables(tb);
     if (!a.tab3) return VFX_EINVAL;
     a.w3 = w3;
     a.segw3 = segw;
+    a.bl3 = bl_eff;
     a.xplane3 = (seg ? nt : 1) * segw * 32;
     a.buf3 = 2 * a.xplane3 + nt * 2 * BM * 32;
     a.tile_lo = 0;
@@ -954,9 +1064,9 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     const dim3 grid(ntiles, nphase * Cout / BM, B);
     g_last_tile = BM * 100000 + BL * 100 + 16;
     (void)x;
-    if (BM == 128) return launch_x3_tile<128, 128, 2, 2>(a, nt, seg, grid, lds, stream);
-    if (BL == 256) return launch_x3_tile<64, 256, 1, 4>(a, nt, seg, grid, lds, stream);
-    return launch_x3_tile<64, 128, 1, 4>(a, nt, seg, grid, lds, stream);
+    if (BM == 128) return launch_x3_tile<128, 128, 2, 2>(a, nt, mode, grid, lds, stream);
+    if (BL == 256) return launch_x3_tile<64, 256, 1, 4>(a, nt, mode, grid, lds, stream);
+    return launch_x3_tile<64, 128, 1, 4>(a, nt, mode, grid, lds, stream);
 }
 
 static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, const vfx_tensor* res,

@@ -359,12 +359,18 @@ class Pipeline:
     """wav batch (B,N) on the device -> restored (B,N): voicefixer/base.py:123-135 for
     B equal-length segments at once (per-utterance peak rule)."""
 
-    def __init__(self, vocoder_state, restorer_state, device="cuda"):
+    def __init__(self, vocoder_state, restorer_state, device="cuda", math="f32"):
         if not torch.cuda.is_available():
             raise VfxError("no HIP device visible: the MI355X path has no CPU fallback")
         self.device = device
-        self.vocoder = VocoderEngine(vocoder_state, device)
+        self.vocoder = VocoderEngine(vocoder_state, device, math)
         self.restorer = RestorerEngine(restorer_state, device)
+        self.math = math
+
+    def set_math(self, math):
+        """"f32" (default) or "bf16x3" (opt-in split-bf16 MFMA products, fp32 accumulation)."""
+        self.vocoder.set_math(math)
+        self.math = math
 
     def wav_to_mel(self, wav, N):
         B = wav.shape[0]

@@ -70,7 +70,7 @@ def pack_gru_whh(w_hh_fwd, w_hh_bwd, kreg, klds, kstr):
 
 def pack_x3(w_packed):
     """[slab][CinPad][Cout] float32 -> the bf16 (hi, lo) planes of VFX_MATH_BF16X3 (include/vfx_hip.h):
-    ``[slab][Cin/16][plane][Cout][16]`` bfloat16 with hi = bf16(w) and lo = bf16(w - hi), both
+    ``[slab][Cin/16][plane][k-half][Cout][8]`` bfloat16 with hi = bf16(w) and lo = bf16(w - hi), both
     round-to-nearest-even (what v_cvt_pk_bf16_f32 does to the activations on the device).
     Cin is zero-padded to a multiple of 16; returns None when Cout is not a multiple of 64."""
     s, cin, cout = w_packed.shape
@@ -83,5 +83,5 @@ def pack_x3(w_packed):
     hi = w.to(torch.bfloat16)
     lo = (w - hi.float()).to(torch.bfloat16)
     planes = torch.stack([hi, lo], dim=1)                       # [slab][plane][Cin][Cout]
-    planes = planes.reshape(s, 2, c16 // 16, 16, cout)          # [slab][plane][chunk][k][Cout]
-    return planes.permute(0, 2, 1, 4, 3).contiguous()           # [slab][chunk][plane][Cout][k]
+    planes = planes.reshape(s, 2, c16 // 16, 2, 8, cout)        # [slab][plane][chunk][k-half][k][Cout]
+    return planes.permute(0, 2, 1, 3, 5, 4).contiguous()        # [slab][chunk][plane][k-half][Cout][k]
