@@ -138,6 +138,7 @@ def test_bf16x3_math_within_parity_bound(seeded_states):
     wav, L = pipe3.vocoder.forward(mel, mel.shape[1])
     torch.cuda.synchronize()
     assert len(pipe3.vocoder._w3) > 60  # every vocoder conv layer got bf16 planes
+    assert pipe3.restorer.center.x3[0] is not None and pipe3.restorer.enc[1][0].x3[1] is not None  # and the UNet
     r = _rms(wav[:, :, :L].cpu().numpy(), g["wav"])
     assert r < RMS_TOL, r
     g = np.load(os.path.join(GOLDEN, "restore_speech_T51.npz"))

@@ -273,6 +273,63 @@ def test_conv2d_3x3_bn_lrelu_residual(cfg):
     assert (got[..., P - 1] == 0).all()  # pad column written as zero
 
 
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 64, 7, True, True), (1, 64, 64, 48, 6, True, False),
+                                 (2, 128, 128, 16, 5, False, True), (1, 384, 384, 8, 3, True, True),
+                                 (1, 768, 384, 8, 3, False, False), (1, 64, 128, 32, 5, True, False)])
+def test_conv2d_3x3_bf16x3(cfg):
+    """3x3 on a pitch map with VFX_MATH_BF16X3: runs as 3 kernel rows x the 3-tap case (Cout 32 / 64 / 128k
+    tiles), with the fused eval-BatchNorm + leaky-ReLU pre-activation, NaN pad columns and NaN guards."""
+    B, Cin, Cout, H, lp, use_res, affine = cfg
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 71)
+    w = _rand((Cout, Cin, 3, 3), 72, (Cin * 9) ** -0.5)
+    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(73))
+    shift = _rand((Cin,), 74, 0.3)
+    res = _rand((B, Cout, H, P - 1), 75) if use_res else None
+    xin = _ref_act(x, _lib.PRE_AFFINE_LRELU, 0.01, scale, shift) if affine else x
+    ref = F.conv2d(xin, w, padding=1)
+    if use_res:
+        ref = ref + res
+    ref = F.leaky_relu(ref, 0.01)
+    xd = ops.guarded(B, Cin, H * P, P + 1 + 264, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xp = _to_pitch(x, lp)
+    if not affine:
+        xp = torch.nan_to_num(xp, nan=0.0)  # without a pre-activation the pad column is a structural zero
+    xd[:, :, :H * P] = xp.to(DEV)
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    rd = torch.nan_to_num(_to_pitch(res, lp), nan=0.0).to(DEV) if use_res else None
+    act = ops.Act(pre=_lib.PRE_AFFINE_LRELU if affine else _lib.PRE_NONE, pre_slope=0.01,
+                  scale=scale.to(DEV) if affine else None, shift=shift.to(DEV) if affine else None,
+                  post=_lib.POST_LRELU, post_slope=0.01)
+    wp = packing.pack_conv2d(w)
+    ops.conv2d(xd, wp.to(DEV), None, yd, H, lp, 3, act, rd, w3=packing.pack_x3(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 1e-4)
+    assert (got[..., P - 1] == 0).all()  # pad column written as zero
+
+
+def test_conv2d_1x1_bf16x3():
+    B, Cin, Cout, H, lp = 2, 64, 32, 16, 6
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 76)
+    w = _rand((Cout, Cin, 1, 1), 77, Cin ** -0.5)
+    bias = _rand((Cout,), 78, 0.1)
+    ref = F.conv2d(x, w, bias)
+    xd = ops.guarded(B, Cin, H * P, 264, DEV)
+    xd[:, :, :H * P] = torch.nan_to_num(_to_pitch(x, lp), nan=0.0).to(DEV)
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    wp = packing.pack_conv2d(w)
+    ops.conv2d(xd, wp.to(DEV), bias.to(DEV), yd, H, lp, 1, None, None, w3=packing.pack_x3(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 16
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 1e-4)
+    assert (got[..., P - 1] == 0).all()
+
+
 def test_conv2d_1x1_bias_residual():
     B, Cin, Cout, H, lp = 2, 64, 32, 16, 6
     P = 1 << lp

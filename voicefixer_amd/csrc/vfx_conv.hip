@@ -89,6 +89,7 @@ struct ConvArgs {
     int xplane3;            // bytes between the hi and the lo plane of the activation tile
     int buf3;               // bytes per LDS buffer (activation planes + weight tile)
     int bl3;                // output positions per tile (< BL when the halo is staged inside the BL columns)
+    int xrow3, wrow3;       // ROWS == 3 (3x3 on a pitch map): byte step of one map row in x / of one kernel row in w3
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -572,15 +573,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // MODE 0: halo tile staged in exactly BL columns (tile = BL - span output positions: no extra staging slot,
 //         for small spans); 1: halo tile of BL + span columns (one extra slot); 2: one BL-column segment per tap.
-template <int BM, int BL, int WGM, int WGL, int NT, int MODE>
+// ROWS 3: a 3x3 convolution on a pitch map runs as the 3-tap (dx) case over "virtual" K-chunks (channel chunk c,
+//         kernel row dy): chunk (c, dy) reads the activations one map row up/down (a scalar offset) and the weight
+//         slabs of kernel row dy -- same LDS footprint and staging as the 1-D k3 case instead of 9 taps at once.
+template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
     constexpr int NTHR = 256;
     constexpr bool SEG = MODE == 2;
     constexpr int XDEPTH = SEG ? 1 : 2;  // activation prefetch distance in steps (= register sets)
     constexpr int NXS = SEG ? (NT * BL * 2) / NTHR : (BL * 2) / NTHR + MODE;  // (position, k-half) units per thread
-    constexpr int NWS = (NT * BM * 4) / NTHR;                                 // 16-byte weight vectors per thread
-    static_assert(WGM * WGL == 4 && (NT * BM * 4) % NTHR == 0 && (BL * 2) % NTHR == 0, "tile/thread mapping");
+    constexpr int WVEC = NT * BM * 4;                     // 16-byte vectors in the weight tile
+    constexpr int NWS = (WVEC + NTHR - 1) / NTHR;         // ... per thread (clamped duplicates when not a multiple)
+    static_assert(WGM * WGL == 4 && (BL * 2) % NTHR == 0 && (ROWS == 1 || (ROWS == 3 && NT == 3 && MODE == 0)),
+                  "tile/thread mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -603,6 +609,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     const int xcs = (int)a.x_cs;
     const float* __restrict__ xb = a.x + (long long)b * a.x_bs;
     const int nchunks = a.Cin >> 4;
+    const int nsteps = nchunks * ROWS;  // K steps: (channel chunk, kernel row)
 
     // ---- per-thread staging slots, fixed for the whole K loop.  Units are enumerated k-half major so that
     // consecutive lanes hold consecutive positions: coalesced loads, contiguous (conflict-free) LDS writes.
@@ -626,7 +633,8 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     int w_voff[NWS];
 #pragma unroll
     for (int j = 0; j < NWS; ++j) {
-        const int v = tid + NTHR * j;       // LDS order [tap][plane][k-half][row], 16 bytes each
+        int v = tid + NTHR * j;             // LDS order [tap][plane][k-half][row], 16 bytes each
+        v = v < WVEC ? v : WVEC - 1;
         const int t = v / (BM * 4);
         const int rem = v - t * (BM * 4);   // = (plane*2 + kh)*BM + row
         const int pk = rem / BM;
@@ -639,8 +647,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
 
     const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
+    // (ROWS 3: the base sits one map row lower so that the scalar row offset dy * xrow3 is never negative --
+    // buffer addressing treats the scalar offset as unsigned)
     const __amdgpu_buffer_rsrc_t xrsrc_real = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(xb) - a.x_guard, (short)0, 0x7fffffff, 0x00020000);
+        const_cast<float*>(xb) - a.x_guard - (ROWS == 3 ? (a.xrow3 >> 2) : 0), (short)0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrsrc_real =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w3), (short)0, 0x7fffffff, 0x00020000);
     // loads of chunks past the end stay in the instruction stream (see the loop) but go through a zero-length
@@ -652,10 +662,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma unroll
     for (int sg = 0; sg < (SEG ? NT : 1); ++sg) {
         const int o = q0 + __builtin_amdgcn_readfirstlane(pt->seg_org[sg]);
-        range_mask |= (o < 0) || (o + segw > a.Lin);
+        const int rowspan = ROWS == 3 ? (a.xrow3 >> 2) : 0;
+        range_mask |= (o - rowspan < 0) || (o + segw + rowspan > a.Lin);
     }
     const bool masked = range_mask || a.in_mask != 0;
-    const float slope = a.pre_act == VFX_PRE_LRELU ? a.pre_slope : 1.f;
+    const float slope = a.pre_act != VFX_PRE_NONE ? a.pre_slope : 1.f;
     const int xplane = a.xplane3, bufb = a.buf3;
     const int wbase = 2 * xplane;  // weight tile follows the two activation planes
 
@@ -666,9 +677,12 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     const int xcs4 = __builtin_amdgcn_readfirstlane(xcs * 4);
     float xr[XDEPTH][NXS][8];
     u32x4 wr[NWS];
-    auto load_x = [&](int c, int set) {
-        const __amdgpu_buffer_rsrc_t xrsrc = c < nchunks ? xrsrc_real : nullrsrc;
-        const int xso = __builtin_amdgcn_readfirstlane(c * 16 * xcs * 4);
+    // step v -> (channel chunk, kernel row)
+    auto chunk_of = [&](int v) { return ROWS == 3 ? (int)(((unsigned)v * 0xAAABu) >> 17) : v; };  // v / 3, v < 2^15
+    auto load_x = [&](int v, int set) {
+        const __amdgpu_buffer_rsrc_t xrsrc = v < nsteps ? xrsrc_real : nullrsrc;
+        const int c = chunk_of(v);
+        const int xso = __builtin_amdgcn_readfirstlane(c * 16 * xcs * 4 + (ROWS == 3 ? (v - 3 * c) * a.xrow3 : 0));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int so = xso + i * xcs4;  // scalar: one s_add per channel row
@@ -677,19 +691,30 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 xr[set][j][i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(xrsrc, x_voff[j], so, 0));
         }
     };
-    auto load_w = [&](int c) {
-        const __amdgpu_buffer_rsrc_t wrsrc = c < nchunks ? wrsrc_real : nullrsrc;
-        const int wso = __builtin_amdgcn_readfirstlane(c * w_cstep);
+    auto load_w = [&](int v) {
+        const __amdgpu_buffer_rsrc_t wrsrc = v < nsteps ? wrsrc_real : nullrsrc;
+        const int c = chunk_of(v);
+        const int wso = __builtin_amdgcn_readfirstlane(c * w_cstep + (ROWS == 3 ? (v - 3 * c) * a.wrow3 : 0));
 #pragma unroll
         for (int j = 0; j < NWS; ++j) wr[j] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_voff[j], wso, 0);
     };
-    auto write_chunk = [&](unsigned char* buf, int set) {
+    const bool affine = a.pre_act == VFX_PRE_AFFINE_LRELU;
+    const float4* aff4 = reinterpret_cast<const float4*>(smem3 + 2 * bufb);  // [Cin] x (scale, shift), two per float4
+    auto write_chunk = [&](unsigned char* buf, int set, int v) {
+        const int c = chunk_of(v);
+        const int roff = ROWS == 3 ? (v - 3 * c - 1) * (a.xrow3 >> 2) : 0;  // this step's row offset in positions
 #pragma unroll
         for (int j = 0; j < NXS; ++j) {
             u32x4 h4, l4;
+            const int kh = (tid + NTHR * j) >= npos ? 1 : 0;  // (clamped duplicates sit in k-half 1)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 float v0 = xr[set][j][2 * i], v1 = xr[set][j][2 * i + 1];
+                if (affine) {  // eval-BatchNorm: (scale, shift) of channels 16c + 8kh + 2i, +1 from the LDS copy
+                    const float4 ss = aff4[c * 8 + kh * 4 + i];
+                    v0 = fmaf(v0, ss.x, ss.y);
+                    v1 = fmaf(v1, ss.z, ss.w);
+                }
                 v0 = v0 > 0.f ? v0 : v0 * slope;
                 v1 = v1 > 0.f ? v1 : v1 * slope;
                 const f32x2 v = {v0, v1};
@@ -700,7 +725,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
                 l4[i] = __builtin_bit_cast(unsigned, l);
             }
             if (masked) {
-                const int l = x_l[j];
+                const int l = x_l[j] + roff;
                 const bool z = (range_mask && (l < 0 || l >= a.Lin)) || (a.in_mask && ((l & a.in_mask) == a.in_mask));
                 if (z) { h4 = u32x4{0, 0, 0, 0}; l4 = u32x4{0, 0, 0, 0}; }
             }
@@ -709,7 +734,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
             __builtin_amdgcn_sched_barrier(0);  // one slot's conversion temporaries at a time
         }
 #pragma unroll
-        for (int j = 0; j < NWS; ++j) *reinterpret_cast<u32x4*>(buf + wbase + (tid + NTHR * j) * 16) = wr[j];
+        for (int j = 0; j < NWS; ++j) {
+            int v = tid + NTHR * j;
+            if (WVEC % NTHR) v = v < WVEC ? v : WVEC - 1;  // duplicates rewrite the tile's last vector
+            *reinterpret_cast<u32x4*>(buf + wbase + v * 16) = wr[j];
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -756,12 +785,17 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         }
     };
 
-    // nchunks is even (host: Cin % 32 == 0).  Every load below is unconditional: a branch around a load makes
+    // nsteps is even (host: Cin % 32 == 0).  Every load below is unconditional: a branch around a load makes
     // the compiler merge "in flight" with "not in flight" at the join and wait for everything (vmcnt(0)), which
-    // would undo the prefetch distance.  Chunks past the end are read through the zero-length resource.
+    // would undo the prefetch distance.  Steps past the end are read through the zero-length resource.
     load_w(0);
     load_x(0, 0);
-    write_chunk(smem3, 0);
+    if (affine) {
+        float2* aff = reinterpret_cast<float2*>(smem3 + 2 * bufb);
+        for (int ch = tid; ch < a.Cin; ch += NTHR) aff[ch] = make_float2(a.pre_scale[ch], a.pre_shift[ch]);
+        __syncthreads();
+    }
+    write_chunk(smem3, 0, 0);
     load_w(1);
     load_x(1, 0);
     if constexpr (XDEPTH == 2) load_x(2, 1);
@@ -770,14 +804,14 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     unsigned long long d_write = 0, d_load = 0, d_mfma = 0, d_bar = 0;
     const unsigned long long t_start = __builtin_amdgcn_s_memtime();
 #endif
-    // step s computes chunk s from LDS buffer s&1; activation set (s&1 or 0) and the weight set hold chunk s+1.
+    // step s computes K-step s from LDS buffer s&1; activation set (s&1 or 0) and the weight set hold step s+1.
     // The last pair runs the same body.  (A peeled tail made LLVM rotate the loop around the common prefix,
     // which cost 64 accumulator moves per iteration and ~40 spilled registers; nounroll keeps it from peeling.)
 #pragma nounroll
-    for (int s = 0; s < nchunks; s += 2) {
+    for (int s = 0; s < nsteps; s += 2) {
         DBG_T(t0);
 #if !(VFX_ABL & 1)
-        write_chunk(smem3 + bufb, 0);
+        write_chunk(smem3 + bufb, 0, s + 1);
 #if VFX_ABL & 8
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -800,7 +834,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #endif
         DBG_T(t4);
 #if !(VFX_ABL & 1)
-        if (s + 2 < nchunks) write_chunk(smem3, XDEPTH - 1);  // (no load inside the branch)
+        if (s + 2 < nsteps) write_chunk(smem3, XDEPTH - 1, s + 2);  // (no load inside the branch)
 #if VFX_ABL & 8
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -837,7 +871,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
         atomicAdd(&g_dbg[0], d_write); atomicAdd(&g_dbg[1], d_load); atomicAdd(&g_dbg[2], d_mfma);
         atomicAdd(&g_dbg[3], d_bar); atomicAdd(&g_dbg[4], t_loop - t_start); atomicAdd(&g_dbg[5], t_end - t_loop);
-        atomicAdd(&g_dbg[6], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)nchunks);
+        atomicAdd(&g_dbg[6], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)nsteps);
     }
 #endif
 }
@@ -972,10 +1006,10 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
 // geometry is outside what conv_x3_kernel covers; the caller then runs the fp32 kernel.
 #define VFX_ENOTSUP (-100)
 
-template <int BM, int BL, int WGM, int WGL, int NT, int MODE>
+template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS = 1>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_x3_kernel<BM, BL, WGM, WGL, NT, MODE>;
+    auto kern = conv_x3_kernel<BM, BL, WGM, WGL, NT, MODE, ROWS>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -988,7 +1022,8 @@ static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s
 }
 
 template <int BM, int BL, int WGM, int WGL>
-static int launch_x3_tile(const ConvArgs& a, int nt, int mode, dim3 grid, size_t lds, hipStream_t s) {
+static int launch_x3_tile(const ConvArgs& a, int nt, int mode, int rows, dim3 grid, size_t lds, hipStream_t s) {
+    if (rows == 3) return launch_x3_one<BM, BL, WGM, WGL, 3, 0, 3>(a, grid, lds, s);
 #define VFX_X3(NT_)                                                                                  \
     if (nt == NT_)                                                                                   \
         return mode == 2   ? launch_x3_one<BM, BL, WGM, WGL, NT_, 2>(a, grid, lds, s)                \
@@ -1001,11 +1036,26 @@ static int launch_x3_tile(const ConvArgs& a, int nt, int mode, dim3 grid, size_t
     return VFX_ENOTSUP;
 }
 
-static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const PhaseSpec* phs, const void* w3,
+static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const PhaseSpec* phs_in, const void* w3,
                          hipStream_t stream) {
     const int Cin = a.Cin, Cout = a.Cout, B = a.B, Lq = a.Lq, Lin = a.Lin;
-    if (!w3 || !vfx_aligned16(w3) || Cin % 32 != 0 || Cout % 64 != 0) return VFX_ENOTSUP;
-    if (a.pad_mode == VFX_PAD_REFLECT || a.pre_act == VFX_PRE_AFFINE_LRELU) return VFX_ENOTSUP;
+    if (!w3 || !vfx_aligned16(w3) || Cin % 32 != 0 || Cout % 32 != 0) return VFX_ENOTSUP;
+    if (a.pad_mode == VFX_PAD_REFLECT) return VFX_ENOTSUP;
+    // 3x3 on a pitch map (9 taps (ky-1)*P + (kx-1), slab ky*3+kx) -> 3 kernel rows x the 3-tap dx case
+    int rows = 1, P = 0;
+    PhaseSpec row_spec;
+    const PhaseSpec* phs = phs_in;
+    if (nphase == 1 && phs_in[0].ntaps == 9) {
+        P = phs_in[0].taps[3].off - phs_in[0].taps[0].off;
+        for (int t = 0; t < 9; ++t)
+            if (phs_in[0].taps[t].off != (t / 3 - 1) * P + (t % 3 - 1) || phs_in[0].taps[t].slab != t) return VFX_ENOTSUP;
+        if (P < 4) return VFX_ENOTSUP;
+        rows = 3;
+        row_spec.ntaps = 3;
+        row_spec.ooff = phs_in[0].ooff;
+        for (int t = 0; t < 3; ++t) { row_spec.taps[t].off = t - 1; row_spec.taps[t].slab = t; }
+        phs = &row_spec;
+    }
     const int nt = phs[0].ntaps;
     if (nt < 1 || nt > 3) return VFX_ENOTSUP;
     int span = 0, seg_lo = 0x7fffffff, seg_hi = -0x7fffffff;
@@ -1026,8 +1076,13 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     const bool seg = mode == 2;
     int BM, BL;
     if (Cout % 128 == 0) { BM = 128; BL = 128; }
-    else if (!seg && Lq >= 4096) { BM = 64; BL = 256; }
-    else { BM = 64; BL = 128; }
+    else if (Cout % 64 == 0) {
+        if (!seg && Lq >= 4096) { BM = 64; BL = 256; }
+        else { BM = 64; BL = 128; }
+    } else {
+        if (seg) return VFX_ENOTSUP;
+        BM = 32; BL = 256;
+    }
     const int segw = mode == 1 ? BL + span : BL;
     const int bl_eff = mode == 0 ? BL - span : BL;
     ConvTables tb;
@@ -1048,25 +1103,34 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     // every tile must be interior with respect to the guard band (loads inside [-guard, Lin + guard))
     const int ntiles = (Lq + bl_eff - 1) / bl_eff;
     const long long g = a.x_guard;
-    if (-(long long)seg_lo > g) return VFX_ENOTSUP;
-    if ((long long)(ntiles - 1) * bl_eff + seg_hi + BL > (long long)Lin + g) return VFX_ENOTSUP;
+    const int rowspan = rows == 3 ? P : 0;
+    if (-(long long)seg_lo + rowspan > g) return VFX_ENOTSUP;
+    if ((long long)(ntiles - 1) * bl_eff + seg_hi + BL + rowspan > (long long)Lin + g) return VFX_ENOTSUP;
     a.tab3 = device_tables(tb);
     if (!a.tab3) return VFX_EINVAL;
+    const int nchunks = Cin / 16;
     a.w3 = w3;
     a.segw3 = segw;
     a.bl3 = bl_eff;
+    a.xrow3 = P * 4;
+    a.wrow3 = 3 * nchunks * (4 * Cout * 16);  // one kernel row = 3 slabs of [Cin/16] chunks
     a.xplane3 = (seg ? nt : 1) * segw * 32;
     a.buf3 = 2 * a.xplane3 + nt * 2 * BM * 32;
     a.tile_lo = 0;
     a.tile_hi = ntiles;
-    const size_t lds = 2ull * a.buf3;
+    const size_t lds = 2ull * a.buf3 + (a.pre_act == VFX_PRE_AFFINE_LRELU ? (size_t)Cin * 8 : 0);
     if (lds > 160 * 1024) return VFX_ENOTSUP;
     const dim3 grid(ntiles, nphase * Cout / BM, B);
     g_last_tile = BM * 100000 + BL * 100 + 16;
     (void)x;
-    if (BM == 128) return launch_x3_tile<128, 128, 2, 2>(a, nt, mode, grid, lds, stream);
-    if (BL == 256) return launch_x3_tile<64, 256, 1, 4>(a, nt, mode, grid, lds, stream);
-    return launch_x3_tile<64, 128, 1, 4>(a, nt, mode, grid, lds, stream);
+    if (BM == 128) return launch_x3_tile<128, 128, 2, 2>(a, nt, mode, rows, grid, lds, stream);
+    if (BM == 32) {
+        if (rows == 3) return launch_x3_one<32, 256, 1, 4, 3, 0, 3>(a, grid, lds, stream);
+        if (nt == 1 && mode == 0) return launch_x3_one<32, 256, 1, 4, 1, 0, 1>(a, grid, lds, stream);
+        return VFX_ENOTSUP;
+    }
+    if (BL == 256) return launch_x3_tile<64, 256, 1, 4>(a, nt, mode, rows, grid, lds, stream);
+    return launch_x3_tile<64, 128, 1, 4>(a, nt, mode, rows, grid, lds, stream);
 }
 
 static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, const vfx_tensor* res,

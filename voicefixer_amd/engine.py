@@ -172,17 +172,30 @@ class _ConvBlock:
         if (p + ".shortcut.weight") in sd:
             self.shortcut = (_dev(packing.pack_conv2d(sd[p + ".shortcut.weight"]), device),
                              _dev(sd[p + ".shortcut.bias"], device))
+        self.x3 = (None, None, None)
+
+    def set_math(self, math):
+        """bf16 (hi, lo) weight planes for VFX_MATH_BF16X3 (packed once, on first use)."""
+        if math != "bf16x3":
+            self.x3 = (None, None, None)
+            return
+        if not hasattr(self, "_x3_planes"):
+            def pk(w):
+                q = packing.pack_x3(w.cpu()) if w.shape[1] % 32 == 0 else None
+                return None if q is None else q.to(w.device)
+            self._x3_planes = (pk(self.w1), pk(self.w2), pk(self.shortcut[0]) if self.shortcut is not None else None)
+        self.x3 = self._x3_planes
 
     def run(self, x, y1, out, H, lp):
         """x (B,Cin,HP) -> out (B,Cout,HP); y1 scratch (B,Cout,HP).  ``out`` may alias ``x`` when there
         is no shortcut (the residual is read and written at the same position by the same thread)."""
         if self.shortcut is not None:
-            ops.conv2d(x, self.shortcut[0], self.shortcut[1], out, H, lp, 1, None, cin=self.cin)
+            ops.conv2d(x, self.shortcut[0], self.shortcut[1], out, H, lp, 1, None, cin=self.cin, w3=self.x3[2])
             res = out
         else:
             res = x
-        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin)
-        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res)
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0])
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1])
 
 
 class RestorerEngine:
@@ -293,6 +306,15 @@ class RestorerEngine:
         ops.conv1d(x3, self.l4[0], self.l4[1], mask, T, 1, act=self.act_sigmoid)
         return mask
 
+    def set_math(self, math):
+        """"f32" or "bf16x3" for the UNet's 3x3 / 1x1 convolutions (the denoiser and the transposed convolutions
+        stay fp32: 1 % of the FLOPs)."""
+        if math not in ("f32", "bf16x3"):
+            raise ValueError("math must be 'f32' or 'bf16x3'")
+        for grp in list(self.enc) + [[self.center]] + [d[2] for d in self.dec] + [[self.after]]:
+            for blk in grp:
+                blk.set_math(math)
+
     # -- ResUNet ---------------------------------------------------------------------
     def unet(self, u, Tp):
         """u (B,2,Tp*128) pitch map -> (B,1,Tp*128)."""
@@ -365,11 +387,13 @@ class Pipeline:
         self.device = device
         self.vocoder = VocoderEngine(vocoder_state, device, math)
         self.restorer = RestorerEngine(restorer_state, device)
+        self.restorer.set_math(math)
         self.math = math
 
     def set_math(self, math):
         """"f32" (default) or "bf16x3" (opt-in split-bf16 MFMA products, fp32 accumulation)."""
         self.vocoder.set_math(math)
+        self.restorer.set_math(math)
         self.math = math
 
     def wav_to_mel(self, wav, N):

@@ -72,9 +72,9 @@ def pack_x3(w_packed):
     """[slab][CinPad][Cout] float32 -> the bf16 (hi, lo) planes of VFX_MATH_BF16X3 (include/vfx_hip.h):
     ``[slab][Cin/16][plane][k-half][Cout][8]`` bfloat16 with hi = bf16(w) and lo = bf16(w - hi), both
     round-to-nearest-even (what v_cvt_pk_bf16_f32 does to the activations on the device).
-    Cin is zero-padded to a multiple of 16; returns None when Cout is not a multiple of 64."""
+    Cin is zero-padded to a multiple of 16; returns None when Cout is not a multiple of 32."""
     s, cin, cout = w_packed.shape
-    if cout % 64 != 0:
+    if cout % 32 != 0:
         return None
     c16 = (cin + 15) // 16 * 16
     w = w_packed.float()
