@@ -576,6 +576,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // ROWS 3: a 3x3 convolution on a pitch map runs as the 3-tap (dx) case over "virtual" K-chunks (channel chunk c,
 //         kernel row dy): chunk (c, dy) reads the activations one map row up/down (a scalar offset) and the weight
 //         slabs of kernel row dy -- same LDS footprint and staging as the 1-D k3 case instead of 9 taps at once.
+//         With NT = 1 the same mechanism splits a widely dilated 1-D k3 (taps at -d, 0, +d: no shared halo) into
+//         three single-tap K-steps per channel chunk: 33 KB of LDS per workgroup instead of 98 KB, three
+//         workgroups per CU instead of one.
 template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     constexpr int NXS = SEG ? (NT * BL * 2) / NTHR : (BL * 2) / NTHR + MODE;  // (position, k-half) units per thread
     constexpr int WVEC = NT * BM * 4;                     // 16-byte vectors in the weight tile
     constexpr int NWS = (WVEC + NTHR - 1) / NTHR;         // ... per thread (clamped duplicates when not a multiple)
-    static_assert(WGM * WGL == 4 && (BL * 2) % NTHR == 0 && (ROWS == 1 || (ROWS == 3 && NT == 3 && MODE == 0)),
+    static_assert(WGM * WGL == 4 && (BL * 2) % NTHR == 0 && (ROWS == 1 || (ROWS == 3 && (NT == 3 || NT == 1) && MODE == 0)),
                   "tile/thread mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
@@ -1023,7 +1026,8 @@ static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s
 
 template <int BM, int BL, int WGM, int WGL>
 static int launch_x3_tile(const ConvArgs& a, int nt, int mode, int rows, dim3 grid, size_t lds, hipStream_t s) {
-    if (rows == 3) return launch_x3_one<BM, BL, WGM, WGL, 3, 0, 3>(a, grid, lds, s);
+    if (rows == 3 && nt == 3) return launch_x3_one<BM, BL, WGM, WGL, 3, 0, 3>(a, grid, lds, s);
+    if (rows == 3) return launch_x3_one<BM, BL, WGM, WGL, 1, 0, 3>(a, grid, lds, s);
 #define VFX_X3(NT_)                                                                                  \
     if (nt == NT_)                                                                                   \
         return mode == 2   ? launch_x3_one<BM, BL, WGM, WGL, NT_, 2>(a, grid, lds, s)                \
@@ -1054,6 +1058,21 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
         row_spec.ntaps = 3;
         row_spec.ooff = phs_in[0].ooff;
         for (int t = 0; t < 3; ++t) { row_spec.taps[t].off = t - 1; row_spec.taps[t].slab = t; }
+        phs = &row_spec;
+    }
+    int wrow_slabs = 3;  // slabs per "row" step
+    static const bool tapsplit_all = getenv("VFX_X3_TAPSPLIT") && atoi(getenv("VFX_X3_TAPSPLIT")) != 0;  // development
+    if (rows == 1 && nphase == 1 && phs[0].ntaps == 3 && phs[0].taps[0].slab == 0 && phs[0].taps[1].slab == 1 &&
+        phs[0].taps[2].slab == 2 && phs[0].taps[1].off == 0 && phs[0].taps[0].off == -phs[0].taps[2].off &&
+        (phs[0].taps[2].off > 60 || (tapsplit_all && phs[0].taps[2].off > 0))) {
+        // widely dilated k3: one tap per K-step (see the kernel comment)
+        rows = 3;
+        P = phs[0].taps[2].off;
+        wrow_slabs = 1;
+        row_spec.ntaps = 1;
+        row_spec.ooff = phs[0].ooff;
+        row_spec.taps[0].off = 0;
+        row_spec.taps[0].slab = 0;
         phs = &row_spec;
     }
     const int nt = phs[0].ntaps;
@@ -1113,7 +1132,7 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     a.segw3 = segw;
     a.bl3 = bl_eff;
     a.xrow3 = P * 4;
-    a.wrow3 = 3 * nchunks * (4 * Cout * 16);  // one kernel row = 3 slabs of [Cin/16] chunks
+    a.wrow3 = wrow_slabs * nchunks * (4 * Cout * 16);  // one kernel row = 3 slabs (one tap = 1 slab) of [Cin/16] chunks
     a.xplane3 = (seg ? nt : 1) * segw * 32;
     a.buf3 = 2 * a.xplane3 + nt * 2 * BM * 32;
     a.tile_lo = 0;
@@ -1125,7 +1144,8 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     (void)x;
     if (BM == 128) return launch_x3_tile<128, 128, 2, 2>(a, nt, mode, rows, grid, lds, stream);
     if (BM == 32) {
-        if (rows == 3) return launch_x3_one<32, 256, 1, 4, 3, 0, 3>(a, grid, lds, stream);
+        if (rows == 3 && nt == 3) return launch_x3_one<32, 256, 1, 4, 3, 0, 3>(a, grid, lds, stream);
+        if (rows == 3) return VFX_ENOTSUP;
         if (nt == 1 && mode == 0) return launch_x3_one<32, 256, 1, 4, 1, 0, 1>(a, grid, lds, stream);
         return VFX_ENOTSUP;
     }
