@@ -67,6 +67,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue consecutive steps (batches) round-robin on this many HIP streams")
+    ap.add_argument("--no-events", action="store_true",
+                    help="development: time the steps without the per-launch HIP events (no roofline object)")
+    ap.add_argument("--no-bf16x3", action="store_true",
+                    help="skip the auxiliary timing of the opt-in bf16x3 arithmetic (reported beside the fp32 headline)")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32",
                     help="contraction arithmetic: exact fp32 MFMA (default, the headline) or the opt-in split-bf16 "
                          "products with fp32 accumulation (DESIGN.md 3.4)")
@@ -111,12 +115,16 @@ def main():
 
     out = run_steps(args.warmup)
     barrier()
-    ops.PROFILE = []
+    ops.PROFILE = None if args.no_events else []
     t0 = time.perf_counter()
     out = run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
+    if prof is None:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "events": False}), flush=True)
+        return
     assert torch.isfinite(out).all()
 
     if dist is not None:
@@ -190,6 +198,23 @@ def main():
         "path_tflops": round(2.0 * path_macs(n) * args.batch * world * args.steps / dt / 1e12, 2),
         "roofline": roofline,
     }
+
+    if world == 1 and args.math == "f32" and not args.no_bf16x3:
+        # auxiliary, NOT the headline: the same workload with the opt-in split-bf16 contraction (three bf16 MFMA
+        # products per fp32 product, fp32 accumulation), and its waveform distance from the fp32 run
+        pipe.set_math("bf16x3")
+        run_steps(1)
+        barrier()
+        t1 = time.perf_counter()
+        out3 = run_steps(args.steps)
+        barrier()
+        dt3 = time.perf_counter() - t1
+        pipe.set_math("f32")
+        line["bf16x3_optin"] = {
+            "value": round(args.batch * args.seconds * args.steps / dt3, 2), "unit": "x real-time",
+            "ms_per_step": round(dt3 / args.steps * 1e3, 3),
+            "rms_vs_f32": float(torch.sqrt(torch.mean((out3 - out) ** 2))),
+            "note": "opt-in VoiceFixer.set_math('bf16x3'); parity bound 1e-3 RMS"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle  # checker/baseline only

@@ -82,6 +82,7 @@ struct ConvArgs {
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
     int x_guard;            // readable elements before every input row (vfx_tensor.guard)
+    int res_init;           // 1: plain output map (out = q) -> the residual is loaded into the accumulators up front
     // ---- bf16x3 instance (conv_x3_kernel) only
     const void* w3;         // weights as bf16 hi/lo planes: [slab][Cin/16][plane][k-half][Cout][8]
     const ConvTables* tab3; // tap tables in POSITIONS (no 4-alignment: the x3 staging moves single floats)
@@ -280,13 +281,32 @@ __device__ __forceinline__ void acc_init_bias(f32x16 (&acc)[RM][RL], const float
         }
 }
 
+// ... and, for plain output maps (out = q), at bias + residual: the residual tile of this workgroup is read while
+// the first K-chunk is staged instead of in 16 load->use round trips per wave after the K loop.  (In-place
+// residual updates stay safe: a workgroup reads and writes only its own tile.)
+template <int RM, int RL>
+__device__ __forceinline__ void acc_init_residual(f32x16 (&acc)[RM][RL], const float* __restrict__ rb, int rcs,
+                                                  int rls, int nbase, int qbase, int qend) {
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        const int q = qbase + j * 32;
+        if (q < qend) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    acc[i][j][r] += rb[(nbase + i * 32 + (r & 3) + 8 * (r >> 2)) * rcs + q * rls];
+        }
+    }
+}
+
 // ---- epilogue of one tile (bias is already in the accumulators)
 template <int BM, int BL, int WGM, int WGL>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BL / WGL / 32], int q0,
                                               int m0, int b, int wm, int wl, int lo, int hi, int ooff, int qend) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
     float* __restrict__ yb = a.y + (long long)b * a.y_bs;
-    const float* __restrict__ rb = a.res ? a.res + (long long)b * a.r_bs : nullptr;
+    const float* __restrict__ rb = (a.res && !a.res_init) ? a.res + (long long)b * a.r_bs : nullptr;
     const int nbase = m0 + wm * WMT + 4 * hi;
     if (a.post_act <= VFX_POST_LRELU) {
         // hot case (no / leaky-ReLU activation): unrolled, 32-bit offsets from the per-batch base, one
@@ -430,6 +450,9 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 
     f32x16 acc[RM][RL];
     acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
+    if (a.res && a.res_init)
+        acc_init_residual<RM, RL>(acc, a.res + (long long)b * a.r_bs, (int)a.r_cs, (int)a.r_ls, m0 + wm * WMT + 4 * hi,
+                                  q0 + wl * WLT + lo, a.Lq);
 
     const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
     const int a_col = wm * WMT + lo;  // column into the weight tile row
@@ -648,6 +671,11 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 
     f32x16 acc[RM][RL];
     acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
+    if (a.res && a.res_init) {
+        const int qe0 = q0 + a.bl3;
+        acc_init_residual<RM, RL>(acc, a.res + (long long)b * a.r_bs, (int)a.r_cs, (int)a.r_ls, m0 + wm * WMT + 4 * hi,
+                                  q0 + wl * WLT + lo, qe0 < a.Lq ? qe0 : a.Lq);
+    }
 
     const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
     // (ROWS 3: the base sits one map row lower so that the scalar row offset dy * xrow3 is never negative --
@@ -1179,6 +1207,8 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     a.y_bs = y->bstride; a.y_cs = y->cstride; a.y_ls = y->lstride;
     if (res) { a.r_bs = res->bstride; a.r_cs = res->cstride; a.r_ls = res->lstride; }
     a.q_shift = q_shift; a.q_mask = q_mask; a.o_rs = o_rs; a.o_cs = o_cs;
+    a.res_init = res && nphase == 1 && q_shift == 31 && o_rs == 0 && o_cs == 1 && phs[0].ooff == 0 && Lq <= Lout &&
+                 (long long)Cout * res->cstride + (long long)Lq * res->lstride < (1ll << 31);
     a.pad_mode = pad_mode;
     a.pre_act = act ? act->pre_act : VFX_PRE_NONE;
     a.pre_slope = act ? act->pre_slope : 0.f;
