@@ -82,6 +82,7 @@ struct ConvArgs {
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
     int x_guard;            // readable elements before every input row (vfx_tensor.guard)
+    int nxv;                // activation staging slots per thread this launch needs (host copy of the kernel's nxv)
     int res_init;           // 1: plain output map (out = q) -> the residual is loaded into the accumulators up front
     // ---- bf16x3 instance (conv_x3_kernel) only
     const void* w3;         // weights as bf16 hi/lo planes: [slab][Cin/16][plane][k-half][Cout][8]
@@ -383,11 +384,14 @@ __device__ __forceinline__ int fast_div(int i, int d, float inv) {
     return q;
 }
 
-template <int BM, int BL, int WGM, int WGL, int KC, bool FAST>
+// NXV: activation staging slots per thread the launch needs (1, 2 or the maximum 4; interior instance only):
+// slots are loaded unconditionally, so instantiating the exact count avoids issuing duplicate loads.
+template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4>
 __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kernel(const ConvArgs a) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
     constexpr int NTHR = 64 * WGM * WGL;
-    constexpr int MAXXV = StageCfg<KC>::MAXXV, MAXWV = StageCfg<KC>::MAXWV;
+    constexpr int MAXXV = NXV, MAXWV = StageCfg<KC>::MAXWV;
+    static_assert(NXV <= StageCfg<KC>::MAXXV && (FAST || NXV == StageCfg<KC>::MAXXV), "slot count");
     static_assert((WGM * WGL == 4 || WGM * WGL == 8) && RM >= 1 && RL >= 1, "4 or 8 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -952,10 +956,10 @@ extern "C" int vfx_last_conv_tile(void) { return g_last_tile; }
 
 static inline int floor4(int v) { return v >= 0 ? (v & ~3) : -(((-v) + 3) & ~3); }
 
-template <int BM, int BL, int WGM, int WGL, int KC, bool FAST>
+template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4>
 static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC, FAST>;
+    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC, FAST, NXV>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -972,8 +976,16 @@ template <int BM, int BL, int WGM, int WGL, int KC>
 static int launch_cfg(const ConvArgs& a, int ntiles, int gy, int gz, size_t lds, hipStream_t s) {
     const int nfast = a.tile_hi - a.tile_lo;
     int rc = VFX_OK;
-    if (nfast > 0)
-        rc = launch_one<BM, BL, WGM, WGL, KC, true>(a, dim3((nfast + a.tpw - 1) / a.tpw, gy, gz), lds, s);
+    if (nfast > 0) {
+        const dim3 grid((nfast + a.tpw - 1) / a.tpw, gy, gz);
+        if constexpr (WGM * WGL == 4) {
+            rc = a.nxv <= 1   ? launch_one<BM, BL, WGM, WGL, KC, true, 1>(a, grid, lds, s)
+                 : a.nxv == 2 ? launch_one<BM, BL, WGM, WGL, KC, true, 2>(a, grid, lds, s)
+                              : launch_one<BM, BL, WGM, WGL, KC, true, 4>(a, grid, lds, s);
+        } else {
+            rc = launch_one<BM, BL, WGM, WGL, KC, true, 4>(a, grid, lds, s);
+        }
+    }
     if (rc == VFX_OK && ntiles - nfast > 0)
         rc = launch_one<BM, BL, WGM, WGL, KC, false>(a, dim3(ntiles - nfast, gy, gz), lds, s);
     return rc;
@@ -1260,6 +1272,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         int maxseg = 0;
         for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
         const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * nthr;
+        a.nxv = (int)(((long long)maxseg * KC * (a.segw / 4) + nthr - 1) / nthr);
         const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 16 ? 6 : (KC == 8 ? 4 : 5)) * 4 * nthr;
         if (xfit && wfit) break;
         if (KC == 4) return VFX_ERANGE;
