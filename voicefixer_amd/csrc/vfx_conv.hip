@@ -82,6 +82,7 @@ struct ConvArgs {
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
     int x_guard;            // readable elements before every input row (vfx_tensor.guard)
+    int bl_step;            // tile step along q (= BL, or BL - span for exact-width halo tiles)
     int nxv;                // activation staging slots per thread this launch needs (host copy of the kernel's nxv)
     int res_init;           // 1: plain output map (out = q) -> the residual is loaded into the accumulators up front
     // ---- bf16x3 instance (conv_x3_kernel) only
@@ -402,7 +403,8 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     int tile = blockIdx.x;
     if constexpr (FAST) tile += a.tile_lo;
     else if (tile >= a.tile_lo) tile += a.tile_hi - a.tile_lo;
-    const int q0 = tile * BL;
+    const int q0 = tile * a.bl_step;
+    const int qend = min(a.Lq, q0 + a.bl_step);
     const int m0g = blockIdx.y * BM;
     const int ph = m0g / a.Cout;
     const int m0 = m0g - ph * a.Cout;
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
     if (a.res && a.res_init)
         acc_init_residual<RM, RL>(acc, a.res + (long long)b * a.r_bs, (int)a.r_cs, (int)a.r_ls, m0 + wm * WMT + 4 * hi,
-                                  q0 + wl * WLT + lo, a.Lq);
+                                  q0 + wl * WLT + lo, qend);
 
     const int ooff = __builtin_amdgcn_readfirstlane(pt->ooff);
     const int a_col = wm * WMT + lo;  // column into the weight tile row
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 #if VFX_ABL & 8
     const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
-    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff, a.Lq);
+    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff, qend);
 #if VFX_ABL & 8
     if (tid == 0 && FAST) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -991,7 +993,8 @@ static int launch_cfg(const ConvArgs& a, int ntiles, int gy, int gz, size_t lds,
     return rc;
 }
 
-static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpec* phs, int BL, int KC) {
+static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpec* phs, int BL, int KC,
+                         bool exact = false) {
     // decide halo vs per-tap segments per phase; compute LDS pitch and offsets
     int segw = 0;
     bool halo[VFX_MAXPH];
@@ -1005,7 +1008,7 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
         halo[p] = (long long)BL + span + 3 <= (long long)phs[p].ntaps * (BL + 3);
         int need;
         if (halo[p]) {
-            need = (mn - floor4(mn)) + BL + span;
+            need = exact ? BL : (mn - floor4(mn)) + BL + span;
         } else {
             need = BL + 3;
         }
@@ -1021,7 +1024,7 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
         if (halo[p]) {
             int mn = phs[p].taps[0].off;
             for (int t = 1; t < phs[p].ntaps; ++t) mn = phs[p].taps[t].off < mn ? phs[p].taps[t].off : mn;
-            const int org = floor4(mn);
+            const int org = exact ? mn : floor4(mn);  // exact: unaligned origin (interior instance, buffer loads)
             T.nseg = 1;
             T.seg_org[0] = org;
             for (int t = 0; t < phs[p].ntaps; ++t) {
@@ -1263,36 +1266,53 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     const int nthr = waves8 ? 512 : 256;
     // development switch: VFX_KC16=1 lets 3-tap (or fewer) launches on the 128x128 tile use 16-channel chunks
     static const bool kc16_env = getenv("VFX_KC16") && atoi(getenv("VFX_KC16")) != 0;
+    // Exact-width halo tiles: when the taps of every phase span only a few positions (dilation <= 3, transposed
+    // convolutions, k = 1) the halo is staged INSIDE the BL columns and a tile produces BL - span outputs.  The
+    // activation tile then needs exactly one staging slot per thread (half the loads, conversions and LDS writes
+    // of the BL + halo layout) for <= 6 % idle MFMA columns.  Needs unaligned 16-byte loads, i.e. the interior
+    // instance on every tile (guard band), and no pad-column mask (its fast path assumes aligned vectors).
+    int maxspan = 0;
+    for (int p = 0; p < nphase; ++p) {
+        int mn = phs[p].taps[0].off, mx = mn;
+        for (int t = 1; t < phs[p].ntaps; ++t) {
+            mn = phs[p].taps[t].off < mn ? phs[p].taps[t].off : mn;
+            mx = phs[p].taps[t].off > mx ? phs[p].taps[t].off : mx;
+        }
+        maxspan = mx - mn > maxspan ? mx - mn : maxspan;
+    }
+    static const bool exact_off = getenv("VFX_NO_EXACT") && atoi(getenv("VFX_NO_EXACT")) != 0;  // development
+    bool exact = !exact_off && x->guard > 0 && pad_mode != VFX_PAD_REFLECT && in_mask == 0 && maxspan > 0 &&
+                 maxspan <= 8 && !waves8;
     ConvTables tb;
-    int KC = (kc16_env && maxnt <= 3 && tc.BM == 128 && tc.BL == 128 && !waves8 && Cin % 16 == 0) ? 16 : 8;
+    int KC, ntiles;
+    size_t lds;
     for (;;) {
-        std::memset(&tb, 0, sizeof(tb));
-        int rc = fill_segments(a, tb, nphase, phs, tc.BL, KC);
-        if (rc) return rc;
-        int maxseg = 0;
-        for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
-        const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * nthr;
-        a.nxv = (int)(((long long)maxseg * KC * (a.segw / 4) + nthr - 1) / nthr);
-        const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 16 ? 6 : (KC == 8 ? 4 : 5)) * 4 * nthr;
-        if (xfit && wfit) break;
-        if (KC == 4) return VFX_ERANGE;
-        KC = KC == 16 ? 8 : 4;
-    }
-    a.tab = device_tables(tb);
-    if (!a.tab) return VFX_EINVAL;
-    a.ws_floats = maxnt * KC * tc.BM;
-    size_t lds = (2ull * (a.xs_floats + a.ws_floats) + 2ull * a.CinPad) * sizeof(float);
-    {
-        // development knob: VFX_LDS_MIN_KB pads the request to limit workgroups per CU (occupancy studies)
-        static const long pad_kb = getenv("VFX_LDS_MIN_KB") ? atol(getenv("VFX_LDS_MIN_KB")) : 0;
-        if (pad_kb > 0 && lds < (size_t)pad_kb * 1024) lds = (size_t)pad_kb * 1024;
-    }
-    if (lds > 160 * 1024) return VFX_ERANGE;
+        KC = (kc16_env && maxnt <= 3 && tc.BM == 128 && tc.BL == 128 && !waves8 && Cin % 16 == 0) ? 16 : 8;
+        for (;;) {
+            std::memset(&tb, 0, sizeof(tb));
+            int rc = fill_segments(a, tb, nphase, phs, tc.BL, KC, exact);
+            if (rc) return rc;
+            int maxseg = 0;
+            for (int p = 0; p < nphase; ++p) maxseg = tb.ph[p].nseg > maxseg ? tb.ph[p].nseg : maxseg;
+            const bool xfit = (long long)maxseg * KC * (a.segw / 4) <= 4 * nthr;
+            a.nxv = (int)(((long long)maxseg * KC * (a.segw / 4) + nthr - 1) / nthr);
+            const bool wfit = (long long)maxnt * KC * tc.BM <= (KC == 16 ? 6 : (KC == 8 ? 4 : 5)) * 4 * nthr;
+            if (xfit && wfit) break;
+            if (KC == 4) return VFX_ERANGE;
+            KC = KC == 16 ? 8 : 4;
+        }
+        a.ws_floats = maxnt * KC * tc.BM;
+        lds = (2ull * (a.xs_floats + a.ws_floats) + 2ull * a.CinPad) * sizeof(float);
+        {
+            // development knob: VFX_LDS_MIN_KB pads the request to limit workgroups per CU (occupancy studies)
+            static const long pad_kb = getenv("VFX_LDS_MIN_KB") ? atol(getenv("VFX_LDS_MIN_KB")) : 0;
+            if (pad_kb > 0 && lds < (size_t)pad_kb * 1024) lds = (size_t)pad_kb * 1024;
+        }
+        if (lds > 160 * 1024) return VFX_ERANGE;
 
-    g_last_tile = tc.BM * 100000 + tc.BL * 100 + KC;
-    // interior tiles: all staged vectors of all phases inside [0, Lin) and no channel tail
-    const int ntiles = (Lq + tc.BL - 1) / tc.BL;
-    {
+        // interior tiles: all staged vectors of all phases inside [0, Lin) and no channel tail
+        a.bl_step = exact ? tc.BL - maxspan : tc.BL;
+        ntiles = (Lq + a.bl_step - 1) / a.bl_step;
         int seg_lo = 0x7fffffff, seg_hi = -0x7fffffff;
         for (int p = 0; p < nphase; ++p)
             for (int sg = 0; sg < tb.ph[p].nseg; ++sg) {
@@ -1302,14 +1322,19 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         // loads are safe inside [-guard, Lin + guard); values outside [0, Lin) are masked in the kernel
         const long long g = (x->guard > 0 && pad_mode != VFX_PAD_REFLECT) ? x->guard : 0;
         const long long need_lo = -(long long)seg_lo - g;  // q0 >= need_lo
-        int tlo = need_lo > 0 ? (int)((need_lo + tc.BL - 1) / tc.BL) : 0;
+        int tlo = need_lo > 0 ? (int)((need_lo + a.bl_step - 1) / a.bl_step) : 0;
         const long long room = (long long)Lin + g - seg_hi - a.segw;
-        int thi = room >= 0 ? (int)(room / tc.BL) + 1 : 0;
+        int thi = room >= 0 ? (int)(room / a.bl_step) + 1 : 0;
         if (thi > ntiles) thi = ntiles;
         if (tlo > thi || Cin % KC != 0) { tlo = 0; thi = 0; }
         a.tile_lo = tlo;
         a.tile_hi = thi;
+        if (exact && !(tlo == 0 && thi == ntiles)) { exact = false; continue; }  // boundary tiles: aligned layout
+        break;
     }
+    a.tab = device_tables(tb);
+    if (!a.tab) return VFX_EINVAL;
+    g_last_tile = tc.BM * 100000 + tc.BL * 100 + KC;
     {
         // tiles per FAST workgroup: as many as keeps >= ~1024 workgroups in flight, at most 8
         const long long nwg1 = (long long)(a.tile_hi - a.tile_lo) * (nphase * Cout / tc.BM) * B;
