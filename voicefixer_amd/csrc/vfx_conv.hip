@@ -385,7 +385,7 @@ __device__ __forceinline__ int fast_div(int i, int d, float inv) {
     return q;
 }
 
-// NXV: activation staging slots per thread the launch needs (1, 2 or the maximum 4; interior instance only):
+// NXV: activation staging slots per thread the launch needs (1 .. 4; interior instance only):
 // slots are loaded unconditionally, so instantiating the exact count avoids issuing duplicate loads.
 template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4>
 __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kernel(const ConvArgs a) {
@@ -983,6 +983,7 @@ static int launch_cfg(const ConvArgs& a, int ntiles, int gy, int gz, size_t lds,
         if constexpr (WGM * WGL == 4) {
             rc = a.nxv <= 1   ? launch_one<BM, BL, WGM, WGL, KC, true, 1>(a, grid, lds, s)
                  : a.nxv == 2 ? launch_one<BM, BL, WGM, WGL, KC, true, 2>(a, grid, lds, s)
+                 : a.nxv == 3 ? launch_one<BM, BL, WGM, WGL, KC, true, 3>(a, grid, lds, s)
                               : launch_one<BM, BL, WGM, WGL, KC, true, 4>(a, grid, lds, s);
         } else {
             rc = launch_one<BM, BL, WGM, WGL, KC, true, 4>(a, grid, lds, s);
@@ -1010,7 +1011,7 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
         if (halo[p]) {
             need = exact ? BL : (mn - floor4(mn)) + BL + span;
         } else {
-            need = BL + 3;
+            need = exact ? BL : BL + 3;
         }
         need = (need + 3) & ~3;
         segw = need > segw ? need : segw;
@@ -1034,7 +1035,7 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
         } else {
             T.nseg = phs[p].ntaps;
             for (int t = 0; t < phs[p].ntaps; ++t) {
-                const int org = floor4(phs[p].taps[t].off);
+                const int org = exact ? phs[p].taps[t].off : floor4(phs[p].taps[t].off);
                 T.seg_org[t] = org;
                 T.tap_lds[t] = t * KC * segw + (phs[p].taps[t].off - org);
                 T.tap_w[t] = phs[p].taps[t].slab;
@@ -1271,7 +1272,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     // activation tile then needs exactly one staging slot per thread (half the loads, conversions and LDS writes
     // of the BL + halo layout) for <= 6 % idle MFMA columns.  Needs unaligned 16-byte loads, i.e. the interior
     // instance on every tile (guard band), and no pad-column mask (its fast path assumes aligned vectors).
+    // Launches whose phases all stage one segment per tap (wide dilations) get exact BL-wide segments the same
+    // way (no alignment slack: 3 slots instead of 4), at no cost in columns.
     int maxspan = 0;
+    bool all_segments = true;
     for (int p = 0; p < nphase; ++p) {
         int mn = phs[p].taps[0].off, mx = mn;
         for (int t = 1; t < phs[p].ntaps; ++t) {
@@ -1279,10 +1283,11 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
             mx = phs[p].taps[t].off > mx ? phs[p].taps[t].off : mx;
         }
         maxspan = mx - mn > maxspan ? mx - mn : maxspan;
+        all_segments &= !((long long)tc.BL + (mx - mn) + 3 <= (long long)phs[p].ntaps * (tc.BL + 3));
     }
-    static const bool exact_off = getenv("VFX_NO_EXACT") && atoi(getenv("VFX_NO_EXACT")) != 0;  // development
-    bool exact = !exact_off && x->guard > 0 && pad_mode != VFX_PAD_REFLECT && in_mask == 0 && maxspan > 0 &&
-                 maxspan <= 8 && !waves8;
+    static const int exact_off = getenv("VFX_NO_EXACT") ? atoi(getenv("VFX_NO_EXACT")) : 0;  // development: 1 all, 2 segments
+    bool exact = exact_off != 1 && x->guard > 0 && pad_mode != VFX_PAD_REFLECT && in_mask == 0 && !waves8 &&
+                 ((maxspan > 0 && maxspan <= 8) || (all_segments && exact_off != 2));
     ConvTables tb;
     int KC, ntiles;
     size_t lds;
@@ -1311,7 +1316,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         if (lds > 160 * 1024) return VFX_ERANGE;
 
         // interior tiles: all staged vectors of all phases inside [0, Lin) and no channel tail
-        a.bl_step = exact ? tc.BL - maxspan : tc.BL;
+        a.bl_step = (exact && !all_segments) ? tc.BL - maxspan : tc.BL;
         ntiles = (Lq + a.bl_step - 1) / a.bl_step;
         int seg_lo = 0x7fffffff, seg_hi = -0x7fffffff;
         for (int p = 0; p < nphase; ++p)
