@@ -134,3 +134,22 @@ def test_oracle_mode1_prefilter_length_identity():
     # bins above the cut-off carry (almost) no energy afterwards
     spec = np.abs(np.fft.rfft(y[4096:4096 + 2048] * np.hanning(2048)))
     assert spec[min(cut + 8, 1024):].max() < 1e-3 * spec.max()
+
+
+def test_stream_chunk_plan():
+    """Overlap-add planner: chunks every (chunk - overlap) samples, cover [0, n) exactly, short tails merged."""
+    from voicefixer_amd.api import plan_stream_chunks
+    chunk, ov = 44100 * 30, 44100
+    plan = plan_stream_chunks(44100 * 60 * 30, chunk, ov)          # 30 minutes
+    assert plan[0] == (0, chunk) and all(l == chunk for _, l in plan[:-1])
+    assert all(b[0] - a[0] == chunk - ov for a, b in zip(plan, plan[1:]))
+    assert plan[-1][0] + plan[-1][1] == 44100 * 60 * 30 and len(plan) == 63
+    assert plan_stream_chunks(1000000, chunk, ov) == [(0, 1000000)]          # shorter than one chunk
+    # a tail of <= overlap + 1024 samples is merged into the previous chunk
+    n = chunk + 100
+    assert plan_stream_chunks(n, chunk, ov) == [(0, n)]
+    n = 2 * chunk - ov + 5000
+    p = plan_stream_chunks(n, chunk, ov)
+    assert p[-1][0] + p[-1][1] == n and p[-1][1] > ov + 1024
+    with pytest.raises(ValueError):
+        plan_stream_chunks(10 ** 6, 2000, 1500)

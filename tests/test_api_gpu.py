@@ -168,3 +168,36 @@ def test_restore_folder_matches_per_file_restore(vf, tmp_path):
         assert sr1 == sr2 == 44100 and x1.shape == x2.shape and x1.dtype == np.int16
         # batch-vs-single launches may pick different K-chunk depths (summation order): <= 1 LSB of PCM16
         assert np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1
+
+
+def test_restore_stream_overlap_add(vf):
+    """Overlap-add streaming (BASELINE config 5; a capability beyond the reference): outside the overlaps the
+    output equals the independent restoration of that chunk, inside them it is the linear cross-fade of the two
+    chunks, the callback delivers every sample exactly once and in order."""
+    from voicefixer_amd.api import plan_stream_chunks
+    rng = np.random.default_rng(9)
+    n = 44100 * 5 + 1234
+    wav = (0.2 * rng.standard_normal(n)).astype(np.float32)
+    cs, os_ = 2.0, 0.25
+    chunk, ov = 88200, 11025
+    got_chunks = []
+    out = vf.restore_stream(wav, chunk_seconds=cs, overlap_seconds=os_, batch_size=2,
+                            on_chunk=lambda a, y: got_chunks.append((a, y)))
+    assert out.shape == (1, n) and out.dtype == np.float32
+    plan = plan_stream_chunks(n, chunk, ov)
+    assert len(plan) == 3
+    singles = [vf.restore_inmem(wav[a:a + l], cuda=True, mode=0) for a, l in plan]
+    w = (np.arange(ov, dtype=np.float32) / ov)[None]
+    for k, (a, l) in enumerate(plan):
+        lo = a + (ov if k > 0 else 0)
+        hi = a + l - (ov if k + 1 < len(plan) else 0)
+        assert _rms(out[:, lo:hi], singles[k][:, lo - a:hi - a]) < 2e-5
+        if k > 0:
+            want = singles[k - 1][:, a - plan[k - 1][0]:a - plan[k - 1][0] + ov] * (1 - w) + singles[k][:, :ov] * w
+            assert _rms(out[:, a:a + ov], want) < 2e-5
+    pos = 0
+    for a, y in got_chunks:
+        assert a == pos
+        assert np.array_equal(y, out[:, a:a + y.shape[1]])
+        pos += y.shape[1]
+    assert pos == n

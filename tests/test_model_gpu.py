@@ -150,3 +150,28 @@ def test_bf16x3_math_within_parity_bound(seeded_states):
     pipe3.set_math("f32")
     out32 = pipe3.restore(x, x.shape[1])
     assert _rms(out32.cpu().numpy(), g["restored"]) < RMS_TOL
+
+
+def test_batch32_full_size_properties(pipe):
+    """BASELINE config 3 shape (32 x 10 s) through size-independent properties: identical utterances give
+    bit-identical rows (no cross-utterance leakage, no batch-index dependence), a distinct utterance placed in
+    the batch is restored as it is alone, and the peak rule / trim keep every row finite and within [-1, 1]."""
+    n = 441000
+    g = torch.Generator().manual_seed(321)
+    t = torch.arange(n, dtype=torch.float32) / 44100.0
+    a = (0.05 * torch.randn(n, generator=g) + 0.3 * torch.sin(2 * np.pi * 180.0 * t) * (1 + 0.5 * torch.sin(2 * np.pi * 2.5 * t)))
+    b = (0.05 * torch.randn(n, generator=g) + 0.25 * torch.sin(2 * np.pi * 310.0 * t))
+    batch = a[None].repeat(32, 1)
+    batch[17] = b
+    out = pipe.restore(batch.cuda(), n)
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert out.shape == (32, n) and torch.isfinite(out).all() and out.abs().max() <= 1.0
+    same = [i for i in range(32) if i != 17]
+    assert all(torch.equal(out[same[0]], out[i]) for i in same[1:])
+    alone_a = pipe.restore(a[None].cuda(), n).cpu()
+    alone_b = pipe.restore(b[None].cuda(), n).cpu()
+    # (batch size changes the launch geometry of some layers, i.e. the fp32 summation order)
+    assert _rms(out[0].numpy(), alone_a[0].numpy()) < RMS_TOL
+    assert _rms(out[17].numpy(), alone_b[0].numpy()) < RMS_TOL
+    assert _rms(out[17].numpy(), out[0].numpy()) > 1e-3  # the two utterances really differ

@@ -55,6 +55,27 @@ def _load_restorer_state(path):
     return out, (voc or None)  # vf.ckpt may overwrite the vocoder weights
 
 
+def plan_stream_chunks(n, chunk, overlap):
+    """Chunk starts / lengths of the overlap-add streaming mode: chunks of ``chunk`` samples every
+    ``chunk - overlap`` samples; the last one is shorter.  A tail that would be too short to restore
+    (<= overlap + 1024 samples: one cross-fade plus the reflect pad of the STFT) is merged into its predecessor."""
+    if chunk <= overlap + 1024 or overlap < 0:
+        raise ValueError("chunk must exceed overlap + 1024 samples")
+    hop = chunk - overlap
+    plan = []
+    start = 0
+    while True:
+        length = min(chunk, n - start)
+        plan.append([start, length])
+        if start + length >= n:
+            break
+        start += hop
+    if len(plan) > 1 and plan[-1][1] <= overlap + 1024:
+        last = plan.pop()
+        plan[-1][1] = last[0] + last[1] - plan[-1][0]
+    return [tuple(c) for c in plan]
+
+
 class Vocoder(nn.Module):
     """44.1 kHz TFGAN-style universal vocoder (voicefixer/vocoder/base.py)."""
 
@@ -251,6 +272,46 @@ class VoiceFixer(nn.Module):
             for r, k in enumerate(grp):
                 outs[k] = full[r:r + 1]
         return outs
+
+    @torch.no_grad()
+    def restore_stream(self, wav, chunk_seconds=30.0, overlap_seconds=1.0, batch_size=8, mode=0,
+                       your_vocoder_func=None, on_chunk=None):
+        """Long-form restoration with overlap-add (BASELINE config 5; NOT in the reference, whose 30 s segments
+        are hard-cut -- ``restore_inmem`` keeps that behaviour): chunks of ``chunk_seconds`` every
+        ``chunk_seconds - overlap_seconds``, each restored independently (equal-length chunks are batched),
+        consecutive chunks cross-faded linearly over the overlap.  ``on_chunk(start, samples)`` is called with every
+        finished stretch of output in order (bounded latency: the first call comes after the first batch).
+        Returns float32 numpy (1, N)."""
+        self._check_mode(mode)
+        if mode != 0:
+            raise NotImplementedError("restore_stream implements mode 0 (mode 1 changes the chunk length)")
+        pipe = self._get_pipe()
+        wav = np.asarray(wav, dtype=np.float32)
+        n = wav.shape[0]
+        chunk, ov = int(round(chunk_seconds * 44100)), int(round(overlap_seconds * 44100))
+        plan = plan_stream_chunks(n, chunk, ov)
+        out = np.zeros((1, n), np.float32)
+        fade_in = (np.arange(ov, dtype=np.float32) / max(ov, 1))[None]
+        done = 0  # output is final below this sample
+        i = 0
+        while i < len(plan):
+            length = plan[i][1]
+            grp = [c for c in plan[i:i + batch_size] if c[1] == length]
+            seg = torch.from_numpy(np.stack([wav[a:a + length] for a, _ in grp])).to(pipe.device)
+            res = self._restore_segments(pipe, seg, length, mode, your_vocoder_func).cpu().numpy()
+            for (a, _), y in zip(grp, res):
+                y = y[None]
+                if a > 0:  # cross-fade with what the previous chunk left in the overlap
+                    out[:, a:a + ov] = out[:, a:a + ov] * (1.0 - fade_in) + y[:, :ov] * fade_in
+                    out[:, a + ov:a + length] = y[:, ov:]
+                else:
+                    out[:, :length] = y
+                final = a + length - ov if a + length < n else n
+                if on_chunk is not None and final > done:
+                    on_chunk(done, out[:, done:final].copy())
+                done = max(done, final)
+            i += len(grp)
+        return out
 
     def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
