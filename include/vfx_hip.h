@@ -64,8 +64,10 @@ typedef struct {
 #define VFX_MATH_F32 0     /* v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation (default) */
 #define VFX_MATH_BF16X3 1  /* opt-in: every fp32 operand split into two bf16 terms, x*w evaluated as
                               xh*wh + xh*wl + xl*wh on v_mfma_f32_32x32x16_bf16 with fp32 accumulation
-                              (relative product error <= 2^-16); needs w_x3, falls back to fp32 for
-                              geometries the bf16x3 kernel does not cover */
+                              (relative product error <= 2^-16); needs w_x3 and an input guard band
+                              (vfx_tensor.guard >= largest tap offset + tile width), falls back to fp32
+                              per launch for geometries the bf16x3 kernel does not cover (Cin % 32,
+                              reflect padding, more than 3 taps other than 3x3, mixed tap counts) */
 
 typedef struct {
     int pre_act;
@@ -89,8 +91,9 @@ int vfx_version(void);
 uint64_t vfx_launch_count(void);
 
 /* Tile configuration chosen by the most recent conv-family launch of the calling thread,
- * encoded BM*100000 + BL*100 + KC, i.e. the template instance
- * conv_taps_kernel<BM,BL,*,*,KC> a profiler will show (bench.py's roofline bookkeeping). */
+ * encoded BM*100000 + BL*100 + KC, i.e. the template instance family
+ * conv_taps_kernel<BM,BL,*,*,KC,...> a profiler will show (bench.py's roofline bookkeeping);
+ * KC == 16 marks the bf16x3 instance conv_x3_kernel<BM,BL,...>. */
 int vfx_last_conv_tile(void);
 
 /* ---- convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------

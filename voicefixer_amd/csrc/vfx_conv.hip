@@ -1,5 +1,6 @@
 // vfx_conv.hip -- the convolution family of the VoiceFixer path as ONE implicit-GEMM
-// kernel on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak on MI355X).
+// kernel on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TFLOP/s peak on MI355X), plus its opt-in
+// split-bf16 sibling conv_x3_kernel (VFX_MATH_BF16X3, v_mfma_f32_32x32x16_bf16; further down).
 //
 // Every convolution on the path (dilated Conv1d k3, reflect-padded Conv1d k7,
 // polyphase ConvTranspose1d, Conv2d 3x3/1x1 on pitch maps, ConvTranspose2d 3x3 s2,
@@ -17,8 +18,10 @@
 //
 // Workgroup = 256 threads = 4 wave64, each wave owns RM x RL accumulators of 32x32
 // (16 VGPR each).  LDS is double buffered, the next K-chunk travels global -> VGPR while
-// the MFMAs of the current one run, one barrier per chunk; <= 80 KB LDS and <= 256 VGPR
-// keep two workgroups per CU so one stages while the other computes.
+// the MFMAs of the current one run, one barrier per chunk; 33 KB of LDS and 127-155 VGPR
+// keep three to four workgroups per CU so that some stage while others compute.
+// Accumulators start at bias (+ residual); interior tiles (guard bands) run a branch-free
+// instance, instantiated per number of activation staging slots.
 #include "vfx_common.h"
 #include <cstdlib>
 #include <cstring>
