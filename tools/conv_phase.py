@@ -9,7 +9,7 @@ spec = importlib.util.spec_from_file_location("cb", os.path.join(os.path.dirname
 cb = importlib.util.module_from_spec(spec); spec.loader.exec_module(cb)
 h = _lib.lib()
 h.vfx_debug_read.restype = C.c_int
-buf = (C.c_ulonglong * 8)()
+buf = (C.c_ulonglong * 10)()
 B = 8
 X3 = "--x3" in sys.argv
 for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
@@ -28,5 +28,5 @@ for name in [a for a in sys.argv[1:] if not a.startswith("--")]:
     h.vfx_debug_read(buf, 1)
     n, steps = buf[6], buf[7]
     per = lambda v: v / max(steps, 1)
-    print("%-10s WGs=%d chunks/WG=%.0f | per chunk: write %.0f  load %.0f  mfma %.0f  barrier %.0f | per WG: loop %.0f  epilogue %.0f (cycles of s_memtime @100MHz? raw)" %
-          (name, n, steps / max(n, 1), per(buf[0]), per(buf[1]), per(buf[2]), per(buf[3]), buf[4] / max(n, 1), buf[5] / max(n, 1)))
+    print("%-10s WGs=%d chunks/WG=%.0f | per chunk: write %.0f  load %.0f  mfma %.0f  barrier %.0f | per WG: prologue %.0f  loop %.0f  epilogue %.0f (s_memtime units)" %
+          (name, n, steps / max(n, 1), per(buf[0]), per(buf[1]), per(buf[2]), per(buf[3]), buf[8] / max(n, 1), buf[4] / max(n, 1), buf[5] / max(n, 1)))

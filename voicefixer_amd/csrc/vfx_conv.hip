@@ -41,10 +41,10 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 #if VFX_ABL & 8
 // development: per-phase cycle totals (wave 0 of every workgroup), read back with vfx_debug_read
-__device__ unsigned long long g_dbg[8];
+__device__ unsigned long long g_dbg[10];
 extern "C" int vfx_debug_read(unsigned long long* out, int reset) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 8);
-    if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 10);
+    if (reset) { unsigned long long z[10] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
     return 0;
 }
 #define DBG_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
@@ -398,6 +398,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     static_assert(NXV <= StageCfg<KC>::MAXXV && (FAST || NXV == StageCfg<KC>::MAXXV), "slot count");
     static_assert((WGM * WGL == 4 || WGM * WGL == 8) && RM >= 1 && RL >= 1, "4 or 8 waves per workgroup");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    DBG_T(t_entry);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
@@ -580,6 +581,7 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
         atomicAdd(&g_dbg[0], d_write); atomicAdd(&g_dbg[1], d_load); atomicAdd(&g_dbg[2], d_mfma);
         atomicAdd(&g_dbg[3], d_bar); atomicAdd(&g_dbg[4], t_loop - t_start); atomicAdd(&g_dbg[5], t_end - t_loop);
         atomicAdd(&g_dbg[6], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)S);
+        atomicAdd(&g_dbg[8], t_start - t_entry);
     }
 #endif
 }
@@ -623,6 +625,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
     static_assert(WGM * WGL == 4 && (BL * 2) % NTHR == 0 && (ROWS == 1 || (ROWS == 3 && (NT == 3 || NT == 1) && MODE == 0)),
                   "tile/thread mapping");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    DBG_T(t_entry);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lo = lane & 31, hi = lane >> 5;
@@ -912,6 +915,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         atomicAdd(&g_dbg[0], d_write); atomicAdd(&g_dbg[1], d_load); atomicAdd(&g_dbg[2], d_mfma);
         atomicAdd(&g_dbg[3], d_bar); atomicAdd(&g_dbg[4], t_loop - t_start); atomicAdd(&g_dbg[5], t_end - t_loop);
         atomicAdd(&g_dbg[6], 1ull); atomicAdd(&g_dbg[7], (unsigned long long)nsteps);
+        atomicAdd(&g_dbg[8], t_start - t_entry);
     }
 #endif
 }
