@@ -1147,7 +1147,8 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     int BM, BL;
     if (Cout % 128 == 0) { BM = 128; BL = 128; }
     else if (Cout % 64 == 0) {
-        if (!seg && Lq >= 4096) { BM = 64; BL = 256; }
+        static const bool bl128 = getenv("VFX_X3_BL128") && atoi(getenv("VFX_X3_BL128")) != 0;  // development
+        if (!seg && Lq >= 4096 && !bl128) { BM = 64; BL = 256; }
         else { BM = 64; BL = 128; }
     } else {
         if (seg) return VFX_ENOTSUP;
