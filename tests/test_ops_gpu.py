@@ -564,3 +564,61 @@ def test_hf_cut_mode1_prefilter(n):
         assert abs(int(cut[b]) - rcut) <= 1  # float32 summation order may move the threshold crossing by one bin
         if int(cut[b]) == rcut:
             assert np.abs(out[b].cpu().numpy() - ref).max() < 2e-5
+
+
+def test_conv1d_randomised_geometry_sweep():
+    """Seeded sweep over odd geometries (lengths around tile multiples, tiny lengths, every dilation of the
+    ResStack, guarded and unguarded inputs, residual in place, both arithmetics): exercises the exact-width
+    tiles, the per-slot-count instances, the accumulator-initialised bias/residual and the fp32 fallback of
+    bf16x3 launches against the torch operator."""
+    rng = np.random.default_rng(2024)
+    dils = [1, 3, 9, 27, 81, 243, 729, 2187]
+    lens = [5, 63, 124, 126, 127, 128, 129, 250, 252, 253, 254, 255, 257, 1000, 2521, 4099]
+    for case in range(36):
+        B = int(rng.integers(1, 4))
+        Cin = int(rng.choice([32, 64, 96, 128, 256]))
+        Cout = int(rng.choice([32, 64, 128, 256]))
+        L = int(rng.choice(lens))
+        dil = int(rng.choice(dils))
+        k = int(rng.choice([1, 3, 3, 3]))
+        guarded = bool(rng.integers(0, 2))
+        use_res = bool(rng.integers(0, 2))
+        inplace = use_res and Cin == Cout and bool(rng.integers(0, 2))
+        x3 = guarded and Cin % 32 == 0 and bool(rng.integers(0, 2))
+        pre = int(rng.choice([_lib.PRE_NONE, _lib.PRE_LRELU]))
+        post = int(rng.choice([_lib.POST_NONE, _lib.POST_LRELU]))
+        x = _rand((B, Cin, L), 500 + case)
+        w = _rand((Cout, Cin, k), 600 + case, (Cin * k) ** -0.5)
+        bias = _rand((Cout,), 700 + case, 0.1)
+        res = _rand((B, Cout, L), 800 + case) if use_res else None
+        p = (k - 1) // 2 * dil
+        ref = F.conv1d(_ref_act(x, pre, 0.01), w, bias, dilation=dil, padding=p)
+        if use_res:
+            ref = ref + res
+        ref = _ref_post(ref, post, 0.2)
+        lp = (L + 3) // 4 * 4
+        if guarded:
+            xd = ops.guarded(B, Cin, L, p + 264, DEV)
+            xd._vfx_base.fill_(float("nan"))
+            xd[:, :, :L] = x.to(DEV)
+        else:
+            xd = _padded(x, lp)
+        if inplace:
+            yd = _padded(res, lp)
+            rd = yd
+        else:
+            yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+            rd = _padded(res, lp) if use_res else None
+        act = ops.Act(pre=pre, pre_slope=0.01, post=post, post_slope=0.2)
+        wp = packing.pack_conv1d(w)
+        w3 = packing.pack_x3(wp).to(DEV) if x3 else None
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, k, dil, 0, act, rd, w3=w3)
+        torch.cuda.synchronize()
+        tol = 1e-4 if x3 else 2e-5
+        got = yd[:, :, :L].cpu()
+        err = (got - ref).abs().max().item()
+        assert torch.isfinite(got).all() and err <= tol * max(1.0, ref.abs().max().item()), \
+            "case %d: B=%d Cin=%d Cout=%d L=%d k=%d dil=%d guarded=%s res=%s inplace=%s x3=%s err=%g" % (
+                case, B, Cin, Cout, L, k, dil, guarded, use_res, inplace, x3, err)
+        if not inplace:
+            assert torch.isnan(yd[:, :, L:]).all(), "case %d wrote past L" % case
