@@ -180,7 +180,8 @@ def test_convtr1d_bf16x3(cfg):
     wp = packing.pack_convtr1d(w)
     ops.convtr1d(xd, wp.to(DEV), bias.to(DEV), yd, Lin, s, w3=packing.pack_x3(wp).to(DEV))
     torch.cuda.synchronize()
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
+    tiny = B * ((Lin + 127) // 128) * s * max(Cout // 128, 1) <= 96 and Cin * 2 >= 1024
+    assert tiny or _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
     _close(yd[:, :, :Lo], ref, 1e-4)
     assert torch.isnan(yd[:, :, Lo:]).all()
 
@@ -305,7 +306,9 @@ def test_conv2d_3x3_bf16x3(cfg):
     wp = packing.pack_conv2d(w)
     ops.conv2d(xd, wp.to(DEV), None, yd, H, lp, 3, act, rd, w3=packing.pack_x3(wp).to(DEV))
     torch.cuda.synchronize()
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
+    # (launches of <= 96 workgroups with K >= 1024 deliberately fall back to the fp32 split-K path)
+    tiny = (B * H * P + 127) // 128 * max(Cout // 128, 1) <= 96 and Cin * 9 >= 1024
+    assert tiny or _lib.lib().vfx_last_conv_tile() % 100 == 16, "bf16x3 kernel did not run (fp32 fallback)"
     got = _from_pitch(yd, H, lp)
     _close(got[..., : P - 1], ref, 1e-4)
     assert (got[..., P - 1] == 0).all()  # pad column written as zero

@@ -37,6 +37,10 @@ SHAPES = {
     "unet3": ("c2", 128, 128, 256, 5, 0),
     "unet4": ("c2", 256, 256, 128, 4, 0),
     "unet5": ("c2", 384, 384, 64, 3, 0),
+    "unet5q": ("c2", 96, 384, 64, 3, 0),      # unet5 with a quarter of K (split-K what-if, run at 4x batch)
+    "unet4q": ("c2", 64, 256, 128, 4, 0),
+    "unet6": ("c2", 384, 384, 32, 2, 0),
+    "unet6q": ("c2", 96, 384, 32, 2, 0),
     "gru_proj": ("c1", 512, 1536, 1001, 1, 1),
 }
 

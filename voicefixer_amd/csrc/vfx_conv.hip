@@ -85,6 +85,11 @@ struct ConvArgs {
     int tile_lo, tile_hi;   // interior (FAST) tiles along L: [tile_lo, tile_hi)
     int tpw;                // consecutive L-tiles walked by one FAST workgroup
     int x_guard;            // readable elements before every input row (vfx_tensor.guard)
+    // split-K (few workgroups, long K: the deep UNet levels at small batch): grid.z = B * ksplit, split ks reduces
+    // K-chunks [ks*cpp, (ks+1)*cpp) and writes raw partial sums to ws[ks][b][n][q]; splitk_reduce_kernel adds them
+    // in fixed order and applies bias / residual / activation / pad-column zeroing
+    int ksplit, cpp, ws_ls;
+    float* ws;
     int bl_step;            // tile step along q (= BL, or BL - span for exact-width halo tiles)
     int nxv;                // activation staging slots per thread this launch needs (host copy of the kernel's nxv)
     int res_init;           // 1: plain output map (out = q) -> the residual is loaded into the accumulators up front
@@ -380,6 +385,48 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x16 (&acc)[B
     }
 }
 
+// split-K: raw partial sums of one tile -> workspace [ks][b][Cout][ws_ls]
+template <int BM, int BL, int WGM, int WGL>
+__device__ __forceinline__ void conv_epilogue_partial(const ConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BL / WGL / 32],
+                                                      int q0, int m0, int b, int ks, int wm, int wl, int lo, int hi,
+                                                      int qend) {
+    constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
+    float* __restrict__ wb = a.ws + ((long long)ks * a.B + b) * a.Cout * a.ws_ls;
+    const int nbase = m0 + wm * WMT + 4 * hi;
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+        const int q = q0 + wl * WLT + j * 32 + lo;
+        if (q < qend) {
+#pragma unroll
+            for (int i = 0; i < RM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wb[(nbase + i * 32 + (r & 3) + 8 * (r >> 2)) * a.ws_ls + q] = acc[i][j][r];
+        }
+    }
+}
+
+// y[b,n,q] = post(bias[n] + res[b,n,q] + sum_ks ws[ks][b][n][q]), splits added in index order (deterministic)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int ksplit, int ws_ls,
+                                                           const float* __restrict__ bias, const float* res,
+                                                           long long r_bs, long long r_cs, long long r_ls, float* y,
+                                                           long long y_bs, long long y_cs, long long y_ls, int B,
+                                                           int Cout, int Lq, int post_act, float post_slope,
+                                                           int out_mask) {
+    const long long total = (long long)B * Cout * Lq;
+    for (long long e = blockIdx.x * 256ll + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int q = (int)(e % Lq);
+        const long long bn = e / Lq;
+        const int n = (int)(bn % Cout), b = (int)(bn / Cout);
+        float v = bias ? bias[n] : 0.f;
+        if (res) v += res[b * r_bs + n * r_cs + q * r_ls];
+        for (int ks = 0; ks < ksplit; ++ks) v += ws[(((long long)ks * B + b) * Cout + n) * ws_ls + q];
+        v = vfx_post(v, post_act, post_slope);
+        if (out_mask && ((q & out_mask) == out_mask)) v = 0.f;
+        y[b * y_bs + n * y_cs + q * y_ls] = v;
+    }
+}
+
 // exact i / d for 0 <= i < 2^20, 0 < d < 2^12 without the ~40-instruction integer division
 __device__ __forceinline__ int fast_div(int i, int d, float inv) {
     int q = (int)((float)i * inv);
@@ -390,7 +437,9 @@ __device__ __forceinline__ int fast_div(int i, int d, float inv) {
 
 // NXV: activation staging slots per thread the launch needs (1 .. 4; interior instance only):
 // slots are loaded unconditionally, so instantiating the exact count avoids issuing duplicate loads.
-template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4>
+// SPLITK: the launch is cut along K (see ConvArgs::ksplit); a separate instantiation so that the split decode and
+// the partial-sum epilogue cost the regular instances no registers (they sit exactly at the 4-waves-per-SIMD limit).
+template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4, bool SPLITK = false>
 __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kernel(const ConvArgs a) {
     constexpr int WMT = BM / WGM, WLT = BL / WGL, RM = WMT / 32, RL = WLT / 32;
     constexpr int NTHR = 64 * WGM * WGL;
@@ -412,7 +461,9 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     const int m0g = blockIdx.y * BM;
     const int ph = m0g / a.Cout;
     const int m0 = m0g - ph * a.Cout;
-    const int b = blockIdx.z;
+    const int ksplit = SPLITK ? a.ksplit : 1;
+    const int b = SPLITK ? blockIdx.z / ksplit : blockIdx.z;
+    const int ks = SPLITK ? blockIdx.z - b * ksplit : 0;
     const PhaseTab* __restrict__ pt = &a.tab->ph[ph];
     // block-uniform table entries: readfirstlane makes the uniformity provable (SGPRs, scalar branches)
     const int nt = __builtin_amdgcn_readfirstlane(pt->ntaps);
@@ -459,8 +510,8 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     }
 
     f32x16 acc[RM][RL];
-    acc_init_bias<RM, RL>(acc, a.bias, m0 + wm * WMT + 4 * hi);
-    if (a.res && a.res_init)
+    acc_init_bias<RM, RL>(acc, SPLITK ? nullptr : a.bias, m0 + wm * WMT + 4 * hi);
+    if (!SPLITK && a.res && a.res_init)
         acc_init_residual<RM, RL>(acc, a.res + (long long)b * a.r_bs, (int)a.r_cs, (int)a.r_ls, m0 + wm * WMT + 4 * hi,
                                   q0 + wl * WLT + lo, qend);
 
@@ -488,10 +539,11 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     // buffer, the loads of chunk s+2 are issued, and only then the MFMAs of chunk s run.  One barrier
     // per step.  (A multi-tile variant with the epilogue inside this loop was measured SLOWER: its
     // extra live registers cost the third wave per SIMD, which matters more than the saved prologue.)
-    const int S = nchunks;
-    int ch1 = 1, ch2 = 2;  // chunk held in registers / chunk being loaded at the top of step s
+    const int cbase = SPLITK ? ks * a.cpp : 0;                      // first K-chunk of this split
+    const int S = SPLITK ? min(a.cpp, nchunks - cbase) : nchunks;
+    int ch1 = cbase + 1, ch2 = cbase + 2;  // chunk held in registers / chunk being loaded at the top of step s
     constexpr int ti1 = 0, ti2 = 0;
-    stage_load<FAST>(st, a, xb, xcs, 0, 0, xrsrc, wrsrc);
+    stage_load<FAST>(st, a, xb, xcs, cbase * KC, 0, xrsrc, wrsrc);
     // does any staged vector of this tile leave [0, Lin)?  (uniform; only possible with a guard band)
     bool range_mask = false;
     if constexpr (FAST) {
@@ -502,8 +554,8 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     }
     const bool plain = FAST && !range_mask && a.in_mask == 0 && a.pre_act != VFX_PRE_AFFINE_LRELU;
     if (plain) stage_write_plain<NTHR>(st, a, smem, smem + a.xs_floats, nxv, nwv, xtotal, wtotal, tid);
-    else stage_write<FAST, NTHR>(st, a, 0, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
-    if (S > 1) stage_load<FAST>(st, a, xb, xcs, KC, 0, xrsrc, wrsrc);
+    else stage_write<FAST, NTHR>(st, a, cbase * KC, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
+    if (S > 1) stage_load<FAST>(st, a, xb, xcs, (cbase + 1) * KC, 0, xrsrc, wrsrc);
     __syncthreads();
 #if VFX_ABL & 8
     unsigned long long d_write = 0, d_load = 0, d_mfma = 0, d_bar = 0;
@@ -574,7 +626,8 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
 #if VFX_ABL & 8
     const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
-    conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff, qend);
+    if constexpr (SPLITK) conv_epilogue_partial<BM, BL, WGM, WGL>(a, acc, q0, m0, b, ks, wm, wl, lo, hi, qend);
+    else conv_epilogue<BM, BL, WGM, WGL>(a, acc, q0, m0, b, wm, wl, lo, hi, ooff, qend);
 #if VFX_ABL & 8
     if (tid == 0 && FAST) {
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -965,10 +1018,10 @@ extern "C" int vfx_last_conv_tile(void) { return g_last_tile; }
 
 static inline int floor4(int v) { return v >= 0 ? (v & ~3) : -(((-v) + 3) & ~3); }
 
-template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4>
+template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4, bool SPLITK = false>
 static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC, FAST, NXV>;
+    auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC, FAST, NXV, SPLITK>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -985,6 +1038,12 @@ template <int BM, int BL, int WGM, int WGL, int KC>
 static int launch_cfg(const ConvArgs& a, int ntiles, int gy, int gz, size_t lds, hipStream_t s) {
     const int nfast = a.tile_hi - a.tile_lo;
     int rc = VFX_OK;
+    if (a.ksplit > 1) {  // split-K launches (few, small): the generic-slot-count instances
+        if (nfast > 0) rc = launch_one<BM, BL, WGM, WGL, KC, true, 4, true>(a, dim3(nfast, gy, gz), lds, s);
+        if (rc == VFX_OK && ntiles - nfast > 0)
+            rc = launch_one<BM, BL, WGM, WGL, KC, false, 4, true>(a, dim3(ntiles - nfast, gy, gz), lds, s);
+        return rc;
+    }
     if (nfast > 0) {
         const dim3 grid((nfast + a.tpw - 1) / a.tpw, gy, gz);
         if constexpr (WGM * WGL == 4) {
@@ -1055,6 +1114,24 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
     return VFX_OK;
 }
 
+
+
+// split-K workspace: one growing device buffer per stream (allocated during warm-up; a launch that fits reuses it)
+static float* splitk_workspace(hipStream_t s, size_t bytes) {
+    static std::mutex mu;
+    static std::map<hipStream_t, std::pair<float*, size_t>> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    auto& e = pool[s];
+    if (e.second < bytes) {
+        if (e.first) hipFree(e.first);  // (waits for the launches that still use it)
+        e.first = nullptr;
+        e.second = 0;
+        const size_t want = bytes + bytes / 2;
+        if (hipMalloc((void**)&e.first, want) != hipSuccess) { e.first = nullptr; return nullptr; }
+        e.second = want;
+    }
+    return e.first;
+}
 
 // ---- bf16x3 launch path (opt-in per launch, vfx_act.math == VFX_MATH_BF16X3).  Returns VFX_ENOTSUP when the
 // geometry is outside what conv_x3_kernel covers; the caller then runs the fp32 kernel.
@@ -1191,6 +1268,11 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     a.tile_hi = ntiles;
     const size_t lds = 2ull * a.buf3 + (a.pre_act == VFX_PRE_AFFINE_LRELU ? (size_t)Cin * 8 : 0);
     if (lds > 160 * 1024) return VFX_ENOTSUP;
+    // few workgroups and a long K (deep UNet levels, first upsampling stage at small batch): the fp32 kernel
+    // (three to four workgroups per CU, split-K for plain maps) is faster than this instance running a long
+    // serial K loop on a fraction of the chip (measured at batch 1: 23.5 -> 20.4 ms per 10 s utterance)
+    if ((long long)ntiles * (nphase * Cout / BM) * B <= 96 && Cin * (rows == 3 && nt == 3 ? 9 : nt) >= 1024)
+        return VFX_ENOTSUP;
     const dim3 grid(ntiles, nphase * Cout / BM, B);
     g_last_tile = BM * 100000 + BL * 100 + 16;
     (void)x;
@@ -1348,6 +1430,27 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     a.tab = device_tables(tb);
     if (!a.tab) return VFX_EINVAL;
     g_last_tile = tc.BM * 100000 + tc.BL * 100 + KC;
+    // split-K: a launch with few workgroups and a long K (the deep UNet levels at small batch: 48 workgroups x 864
+    // serial K-chunks) is cut along K so that the whole chip works on it; plain output maps only
+    a.ksplit = 1;
+    {
+        static const bool splitk_off = getenv("VFX_NO_SPLITK") && atoi(getenv("VFX_NO_SPLITK")) != 0;  // development
+        const int nchunks = (Cin + KC - 1) / KC;
+        const long long nwg = (long long)ntiles * (nphase * Cout / tc.BM) * B;
+        const bool plain_map = nphase == 1 && q_shift == 31 && o_rs == 0 && o_cs == 1 && phs[0].ooff == 0 && Lq <= Lout;
+        if (!splitk_off && plain_map && nwg <= 192 && nchunks >= 32) {
+            int want = (int)(512 / nwg);
+            if (want > 8) want = 8;
+            if (want > nchunks / 16) want = nchunks / 16;
+            if (want >= 2 && (long long)B * want <= 65535) {
+                a.cpp = (nchunks + want - 1) / want;
+                a.ksplit = (nchunks + a.cpp - 1) / a.cpp;
+                a.ws_ls = Lq;
+                a.ws = splitk_workspace(stream, (size_t)a.ksplit * B * Cout * Lq * sizeof(float));
+                if (!a.ws) a.ksplit = 1;
+            }
+        }
+    }
     {
         // tiles per FAST workgroup: as many as keeps >= ~1024 workgroups in flight, at most 8
         const long long nwg1 = (long long)(a.tile_hi - a.tile_lo) * (nphase * Cout / tc.BM) * B;
@@ -1355,15 +1458,19 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         a.tpw = 1;  // multi-tile workgroups measured slower (register pressure), see the kernel comment
     }
     const int gy = nphase * Cout / tc.BM;
-    if (KC == 16) return launch_cfg<128, 128, 2, 2, 16>(a, ntiles, gy, B, lds, stream);
-#define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                    \
-    if (tc.BM == BM_ && tc.BL == BL_)                                                     \
-        return KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, ntiles, gy, B, lds, stream) \
-                       : launch_cfg<BM_, BL_, WGM_, WGL_, 4>(a, ntiles, gy, B, lds, stream);
-    if (waves8) {
-        VFX_CASE(128, 128, 4, 2)
-        VFX_CASE(64, 256, 2, 4)
-    }
+    const int gz = B * a.ksplit;
+    int rc = VFX_EINVAL;
+    if (KC == 16) rc = launch_cfg<128, 128, 2, 2, 16>(a, ntiles, gy, gz, lds, stream);
+#define VFX_CASE(BM_, BL_, WGM_, WGL_)                                                          \
+    else if (tc.BM == BM_ && tc.BL == BL_)                                                      \
+        rc = KC == 8 ? launch_cfg<BM_, BL_, WGM_, WGL_, 8>(a, ntiles, gy, gz, lds, stream)      \
+                     : launch_cfg<BM_, BL_, WGM_, WGL_, 4>(a, ntiles, gy, gz, lds, stream);
+    else if (waves8 && tc.BM == 128 && tc.BL == 128)
+        rc = KC == 8 ? launch_cfg<128, 128, 4, 2, 8>(a, ntiles, gy, gz, lds, stream)
+                     : launch_cfg<128, 128, 4, 2, 4>(a, ntiles, gy, gz, lds, stream);
+    else if (waves8 && tc.BM == 64 && tc.BL == 256)
+        rc = KC == 8 ? launch_cfg<64, 256, 2, 4, 8>(a, ntiles, gy, gz, lds, stream)
+                     : launch_cfg<64, 256, 2, 4, 4>(a, ntiles, gy, gz, lds, stream);
     VFX_CASE(128, 128, 2, 2)
     VFX_CASE(64, 256, 1, 4)
     VFX_CASE(128, 64, 4, 1)
@@ -1371,7 +1478,14 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     VFX_CASE(64, 64, 2, 2)
     VFX_CASE(32, 128, 1, 4)
 #undef VFX_CASE
-    return VFX_EINVAL;
+    if (rc != VFX_OK || a.ksplit == 1) return rc;
+    const long long total = (long long)B * Cout * Lq;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.ws, a.ksplit, a.ws_ls, a.bias, a.res,
+                       a.r_bs, a.r_cs, a.r_ls, a.y, a.y_bs, a.y_cs, a.y_ls, B, Cout, Lq, a.post_act, a.post_slope,
+                       a.out_mask);
+    VFX_LAUNCHED();
+    return vfx_last_error();
 }
 
 // --------------------------------------------------------------------------------------
