@@ -50,14 +50,23 @@ def _ptr(t):
 
 # Optional per-launch profiling of the MFMA conv family (bench.py roofline bookkeeping):
 # when PROFILE is a list, every conv-family launch is bracketed by HIP events on the launch
-# stream and (tile id, algorithmic MACs, start event, end event) is appended.
+# stream and (tile id, algorithmic MACs, start event, end event) is appended.  EVENT_POOL, if set,
+# is a list of pre-created timing events that are consumed instead of creating new ones (creating
+# an event costs ~10 us of host time, which a launch-bound batch-1 run would otherwise show).
 PROFILE = None
+EVENT_POOL = None
+
+
+def _event():
+    if EVENT_POOL:
+        return EVENT_POOL.pop()
+    return torch.cuda.Event(enable_timing=True)
 
 
 def _prof_begin():
     if PROFILE is None:
         return None
-    e = torch.cuda.Event(enable_timing=True)
+    e = _event()
     e.record()
     return e
 
@@ -65,7 +74,7 @@ def _prof_begin():
 def _prof_end(e0, macs):
     if e0 is None:
         return
-    e1 = torch.cuda.Event(enable_timing=True)
+    e1 = _event()
     e1.record()
     PROFILE.append((_lib.lib().vfx_last_conv_tile(), macs, e0, e1))
 
