@@ -97,6 +97,24 @@ def test_vocoder_forward_and_plugin_hook(vf, seeded_states):
     assert c.shape == (1, gg["wav"].shape[0]) and np.all(c == 0.25)
 
 
+def test_set_math_api(vf, seeded_states):
+    """The opt-in arithmetic through the public classes: same calls, results within the fp32 parity bar."""
+    g = np.load(os.path.join(GOLDEN, "restore_speech_T51.npz"))
+    vf.set_math("bf16x3")
+    try:
+        out = vf.restore_inmem(g["wav"], cuda=True, mode=0)
+    finally:
+        vf.set_math("f32")
+    assert _rms(out, g["restored"]) < 2e-5
+    with pytest.raises(ValueError):
+        vf.set_math("fp8")
+    voc = voicefixer_amd.Vocoder.from_state(seeded_states[0])
+    voc.set_math("bf16x3")
+    gv = np.load(os.path.join(GOLDEN, "vocoder_T101.npz"))
+    wav = voc.forward(torch.from_numpy(gv["mel"]), cuda=False)
+    assert _rms(wav.numpy(), gv["wav"]) < 2e-5
+
+
 def test_restore_batch_bucketing(vf):
     g = torch.Generator().manual_seed(8)
     wavs = [(0.1 * torch.randn(n, generator=g)).numpy() for n in (20000, 30000, 20000, 25000)]

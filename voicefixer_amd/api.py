@@ -102,8 +102,16 @@ class Vocoder(nn.Module):
 
     def _get_engine(self):
         if self._engine is None:
-            self._engine = engine.VocoderEngine(self._state, _device())
+            self._engine = engine.VocoderEngine(self._state, _device(), getattr(self, "math", "f32"))
         return self._engine
+
+    def set_math(self, math):
+        """"f32" (default, exact) or "bf16x3" (opt-in split-bf16 products, see VoiceFixer.set_math)."""
+        if math not in ("f32", "bf16x3"):
+            raise ValueError("math must be 'f32' or 'bf16x3'")
+        self.math = math
+        if self._engine is not None:
+            self._engine.set_math(math)
 
     def forward(self, mel, cuda=False):
         """mel: [B, 1, T, 128] linear, non-normalised -> [B, 1, 441*(T + T%2 + 4)]."""
