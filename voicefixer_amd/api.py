@@ -249,23 +249,34 @@ class VoiceFixer(nn.Module):
         return pipe.restore(seg, n, your_vocoder_func)
 
     @torch.no_grad()
-    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32):
+    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=4):
         """Batched folder inference (not in the reference, which loops files at B=1,
         voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i).
-        Utterances are bucketed by length; each 30 s segment index is one batched launch."""
+        Utterances are bucketed by exact length (results are identical to restoring each alone); every bucket is
+        one batched launch sequence per 30 s segment index.  Buckets go round-robin to ``streams`` HIP streams:
+        with equal lengths the low-occupancy phases of one batch (GRU recurrence, deep UNet levels) overlap the
+        convolutions of the next (+5 %); with ragged lengths (every file its own bucket, B = 1) several utterances
+        run concurrently on a chip that a single one cannot fill."""
         pipe = self._get_pipe()
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
-        # consecutive batches go round-robin to two HIP streams: the low-occupancy phases of one batch
-        # (GRU recurrence, deep UNet levels) overlap the convolutions of the other (+5 % throughput)
-        streams = [torch.cuda.Stream(device=pipe.device) for _ in range(2)]
+        if self.math != "f32":
+            # Open issue (DESIGN.md section 6): with bf16x3 vocoder kernels running on one stream, fp32 UNet launches
+            # on ANOTHER stream occasionally compute one tile from a stale input line (results stay within the parity
+            # bound but are no longer reproducible).  Every single-stream configuration and fp32 on any number of
+            # streams is bit-reproducible, so the opt-in arithmetic stays on one stream.
+            streams = 1
+        pool = [torch.cuda.Stream(device=pipe.device) for _ in range(max(1, int(streams)))]
+        main = torch.cuda.current_stream(pipe.device)
+        for st in pool:
+            st.wait_stream(main)
         pending = []
         i = 0
         nb = 0
         while i < len(order):
             n = len(wavs[order[i]])
             grp = [k for k in order[i:i + batch_size] if len(wavs[k]) == n]
-            with torch.cuda.stream(streams[nb % 2]):
+            with torch.cuda.stream(pool[nb % len(pool)]):
                 parts = []
                 for s0 in range(0, n, SEG_LENGTH):
                     seg = np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH] for k in grp])
