@@ -30,6 +30,9 @@
 #include <string>
 #include <type_traits>
 
+#ifndef VFX_X3_ABL
+#define VFX_X3_ABL 0  // development: ablations of the bf16x3 kernel only (1 = no LDS writes in the loop, 2 = no fragment reads / MFMA)
+#endif
 #ifndef VFX_ABL
 #define VFX_ABL 0  // development ablations: 1 = no staging in the K loop, 2 = no barrier, 4 = no MFMA
 #endif
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
 #pragma nounroll
     for (int s = 0; s < nsteps; s += 2) {
         DBG_T(t0);
-#if !(VFX_ABL & 1)
+#if !(VFX_ABL & 1) && !(VFX_X3_ABL & 1)
         write_chunk(smem3 + bufb, 0, s + 1);
 #if VFX_ABL & 8
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -918,7 +921,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         DBG_T(t1);
 #endif
         DBG_T(t2);
-#if !(VFX_ABL & 4)
+#if !(VFX_ABL & 4) && !(VFX_X3_ABL & 2)
         mfma_chunk(smem3);
 #endif
 #if VFX_ABL & 8
@@ -929,7 +932,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         __syncthreads();
 #endif
         DBG_T(t4);
-#if !(VFX_ABL & 1)
+#if !(VFX_ABL & 1) && !(VFX_X3_ABL & 1)
         if (s + 2 < nsteps) write_chunk(smem3, XDEPTH - 1, s + 2);  // (no load inside the branch)
 #if VFX_ABL & 8
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(const ConvArgs a) {
         DBG_T(t5);
 #endif
         DBG_T(t6);
-#if !(VFX_ABL & 4)
+#if !(VFX_ABL & 4) && !(VFX_X3_ABL & 2)
         mfma_chunk(smem3 + bufb);
 #endif
 #if VFX_ABL & 8
