@@ -223,11 +223,16 @@ def test_restore_stream_overlap_add(vf):
 
 def test_restore_batch_multistream_bit_reproducible(vf):
     """Ragged folder on 4 HIP streams (the restore_batch default) reproduces the single-stream results bit for bit
-    in the default fp32 arithmetic (several B = 1 utterances run concurrently on the chip)."""
+    in both arithmetics (several B = 1 utterances run concurrently on the chip)."""
     rng = np.random.default_rng(12)
     wavs = [(0.1 * rng.standard_normal(int(n))).astype(np.float32) for n in rng.integers(2 * 44100, 4 * 44100, size=8)]
     assert vf.math == "f32"
-    one = vf.restore_batch(wavs, streams=1)
-    for _ in range(2):
-        four = vf.restore_batch(wavs, streams=4)
-        assert all(np.array_equal(a, b) for a, b in zip(one, four))
+    for math in ("f32", "bf16x3"):   # (bf16x3: guards the -fno-slp-vectorize build, DESIGN.md section 6)
+        vf.set_math(math)
+        try:
+            one = vf.restore_batch(wavs, streams=1)
+            for _ in range(2):
+                four = vf.restore_batch(wavs, streams=4)
+                assert all(np.array_equal(a, b) for a, b in zip(one, four)), math
+        finally:
+            vf.set_math("f32")

@@ -260,12 +260,6 @@ class VoiceFixer(nn.Module):
         pipe = self._get_pipe()
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
-        if self.math != "f32":
-            # Open issue: with bf16x3 vocoder kernels running on one stream, fp32 UNet launches
-            # on ANOTHER stream occasionally compute one tile from a stale input line (results stay within the parity
-            # bound but are no longer reproducible).  Every single-stream configuration and fp32 on any number of
-            # streams is bit-reproducible, so the opt-in arithmetic stays on one stream.
-            streams = 1
         pool = [torch.cuda.Stream(device=pipe.device) for _ in range(max(1, int(streams)))]
         main = torch.cuda.current_stream(pipe.device)
         for st in pool:
