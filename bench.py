@@ -6,9 +6,18 @@
 
 One "step" = one pass of the hot path (STFT->mel -> denoiser+ResUNet -> vocoder -> peak/trim)
 over one batch of ``--batch`` synthetic ``--seconds``-second 44.1 kHz utterances already resident
-in HBM (BASELINE configs[2]: batched folder restore, batch 32 x 10 s, mode 0).  With N > 1 each
-rank owns its own batch (utterances shard embarrassingly; no data-path collective): weak scaling,
+in HBM (BASELINE configs[2]: batched folder restore, batch 32 x 10 s, mode 0); consecutive steps
+take DIFFERENT batches (a ring of three resident batches).  With N > 1 each rank owns its own
+batches (utterances shard embarrassingly; no data-path collective): weak scaling,
 ``value`` = all ranks' audio seconds / max-over-ranks wall time.
+
+``host_to_host`` (same JSON line) is the metric as SURVEY.md 8(d) defines it: pinned host waveforms in,
+pinned host waveforms out, H2D of batch k+1 and D2H of batch k-1 on copy streams overlapping the compute of
+batch k (double buffered), everything inside the timed region.  It is never ``value``.
+
+``--scatter`` (BASELINE configs[3], launched under torch.distributed.run): rank 0 owns 256 x N utterances,
+``dist.restore_sharded`` scatters them over RCCL (backend "nccl"), every rank restores its 256 in batches of
+``--batch``, rank 0 gathers; the JSON line then reports the whole job (scatter + compute + gather).
 
 The JSON line also carries
   roofline      -- the dominant kernel (one conv_taps_kernel<BM,BL,..,KC> instance): algorithmic
@@ -57,6 +66,144 @@ def path_macs(n):
     return 488784832 * Tc + 92894304 * Tp + 5210112 * T
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, w1, gpu_out):
+    """The CPU oracle (a port of the reference path onto the same torch-CPU operators; the reference itself cannot
+    travel to the GPU box) on ONE utterance of the batch, B = 1 like voicefixer/__main__.py:187-212, all host
+    threads: 1 warm-up + ``--cpu-reps`` timed repetitions, median reported."""
+    from oracle import oracle  # checker / reported baseline only -- never on the product path
+    from voicefixer_amd import weights
+    vsd, rsd = weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321)
+    threads = torch.get_num_threads()
+    times = []
+    with torch.no_grad():
+        oracle.restore_inmem(w1[: 2 * SR], vsd, rsd)  # thread-pool / allocator warm-up (2 s of audio)
+        for _ in range(max(1, args.cpu_reps)):
+            c0 = time.perf_counter()
+            ref = oracle.restore_inmem(w1, vsd, rsd)
+            times.append(time.perf_counter() - c0)
+    med = sorted(times)[len(times) // 2]
+    err = float(torch.sqrt(torch.mean((gpu_out - torch.from_numpy(ref[0])) ** 2)))
+    return {"value": round(args.seconds / med, 3), "unit": "x real-time", "cores": threads, "kind": "port",
+            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
+            "repetitions_s": [round(t, 2) for t in times],
+            "sample": "1 utterance of %.0f s (one utterance of the last timed batch), B=1 sequential like "
+                      "voicefixer/__main__.py:187-212; median of %d repetitions after one 2 s warm-up; %.1f s of CPU "
+                      "time in total" % (args.seconds, len(times), sum(times)),
+            "rms_vs_gpu": err}
+
+
+def host_to_host_leg(pipe, args, n, dev):
+    """SURVEY.md 8(d) / BASELINE.md 4.6: host-resident float32 waveforms -> host-resident float32 waveforms.
+    Pinned buffers, a different batch every step, H2D / compute / D2H on three streams with event hand-offs
+    (input and output double buffered), all inside the timed region."""
+    B, steps = args.batch, max(args.steps, 2)
+    host_in = [synth_batch(B, n, 5000 + 31 * k, "cpu").pin_memory() for k in range(2)]
+    host_out = [torch.empty((B, n), dtype=torch.float32).pin_memory() for _ in range(2)]
+    dev_in = [torch.empty((B, n), device=dev) for _ in range(2)]
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    ev_in = [torch.cuda.Event() for _ in range(2)]     # H2D of slot k finished
+    ev_free = [torch.cuda.Event() for _ in range(2)]   # compute has consumed dev_in[k]
+    ev_done = [torch.cuda.Event() for _ in range(2)]   # D2H of slot k finished
+    keep = [None, None]
+
+    def run(k_steps):
+        for i in range(k_steps):
+            k = i % 2
+            with torch.cuda.stream(s_in):
+                if i >= 2:
+                    s_in.wait_event(ev_free[k])
+                dev_in[k].copy_(host_in[k], non_blocking=True)
+                ev_in[k].record(s_in)
+            main.wait_event(ev_in[k])
+            y = pipe.restore(dev_in[k], n)
+            ev_free[k].record(main)
+            ev_y = torch.cuda.Event()
+            ev_y.record(main)
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(ev_y)
+                if i >= 2:
+                    ev_done[k].synchronize()  # host_out[k] is free again (bounds the host's run-ahead to two steps)
+                host_out[k].copy_(y, non_blocking=True)
+                ev_done[k].record(s_out)
+            keep[k] = y  # keep the device result alive until its D2H has been issued and finished
+        torch.cuda.synchronize()
+
+    run(2)
+    t0 = time.perf_counter()
+    run(steps)
+    dt = time.perf_counter() - t0
+    pipe.check()
+    assert torch.isfinite(host_out[0]).all() and torch.isfinite(host_out[1]).all()
+    return {"value": round(B * args.seconds * steps / dt, 2), "unit": "x real-time",
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "pcie_bytes_per_step": 2 * B * n * 4,
+            "note": "pinned host waveform -> pinned host waveform, H2D/D2H double buffered on copy streams inside the "
+                    "timed region, a different batch per step (SURVEY.md 8(d)); file decode/encode excluded"}
+
+
+def scatter_job(args, pipe, n, rank, world, dev, dist):
+    """BASELINE configs[3]: rank 0 owns ``utterances_per_gpu * world`` utterances (device-resident on rank 0),
+    scatter over RCCL -> every rank restores its block in batches of ``--batch`` -> gather on rank 0."""
+    from voicefixer_amd import dist as vdist
+    per = args.utterances_per_gpu
+    n_utt = per * world
+    # rank 0 builds the job in chunks of 32 (the synthetic generator is CPU torch)
+    src = None
+    if rank == 0:
+        src = torch.cat([synth_batch(min(32, n_utt - i), n, 2000 + i, dev) for i in range(0, n_utt, 32)], 0)
+    timing = {}
+    # warm-up: one batch through the path on every rank (tables, workspaces, allocator)
+    pipe.restore(synth_batch(min(args.batch, per), n, 77 + rank, dev), n)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = vdist.restore_sharded(lambda w: pipe.restore(w, n), src, n, dev, batch_size=args.batch, timing=timing)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    pipe.check()
+    t = torch.tensor([dt, timing.get("scatter_s", 0.0), timing.get("compute_s", 0.0), timing.get("gather_s", 0.0)],
+                     device=dev, dtype=torch.float64)
+    allt = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(allt, t)
+    if rank == 0:
+        assert out.shape == (n_utt, n) and torch.isfinite(out).all()
+        dmax = max(float(x[0]) for x in allt)
+        line = {
+            "metric": "seconds-of-44.1kHz-audio restored per wall-second",
+            "value": round(n_utt * args.seconds / dmax, 2), "unit": "x real-time", "n_gpus": world,
+            "steps": (per + args.batch - 1) // args.batch, "warmup": 1,
+            "ms_per_step": round(dmax * 1e3 / ((per + args.batch - 1) // args.batch), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
+            "config": {"workload": "batched folder restore sharded via RCCL scatter/gather (BASELINE configs[3]): rank 0 "
+                                   "owns %d x %.0f s utterances, %d per GPU in batches of %d, mode 0, seeded random weights"
+                                   % (n_utt, args.seconds, per, args.batch),
+                       "batch_per_gpu": args.batch, "utterances": n_utt, "utterance_seconds": args.seconds,
+                       "parallelism": "utterance sharding x%d, RCCL point-to-point scatter/gather only" % world},
+            "rccl": {"backend": dist.get_backend(), "world_size": dist.get_world_size()},
+            "per_rank": [{"rank": r, "total_s": round(float(x[0]), 4), "scatter_s": round(float(x[1]), 4),
+                          "compute_s": round(float(x[2]), 4), "gather_s": round(float(x[3]), 4)}
+                         for r, x in enumerate(allt)],
+            "path_tflops": round(2.0 * path_macs(n) * n_utt / dmax / 1e12, 2),
+        }
+        print(json.dumps(line), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +218,11 @@ def main():
                     help="development: time the steps without the per-launch HIP events (no roofline object)")
     ap.add_argument("--no-bf16x3", action="store_true",
                     help="skip the auxiliary timing of the opt-in bf16x3 arithmetic (reported beside the fp32 headline)")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host (PCIe inclusive) timing")
+    ap.add_argument("--scatter", action="store_true",
+                    help="BASELINE configs[3]: rank 0 owns --utterances-per-gpu x N utterances, scatter/gather over RCCL")
+    ap.add_argument("--utterances-per-gpu", type=int, default=256)
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU baseline (median reported)")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32",
                     help="contraction arithmetic: exact fp32 MFMA (default, the headline) or the opt-in split-bf16 "
                          "products with fp32 accumulation (DESIGN.md 3.4)")
@@ -84,16 +236,23 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device("cuda", torch.cuda.current_device())
     dist = None
-    if world > 1:
+    if world > 1 or args.scatter:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from voicefixer_amd import engine, ops, weights
 
     n = int(round(args.seconds * SR))
     pipe = engine.Pipeline(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321), dev, args.math)
-    wav = synth_batch(args.batch, n, 1000 + rank, dev)
+    if args.scatter:
+        return scatter_job(args, pipe, n, rank, world, dev, dist)
+    NRING = 3  # resident input batches; step i restores ring[i % NRING]
+    ring = [synth_batch(args.batch, n, 1000 + 97 * k + rank, dev) for k in range(NRING)]
+    wav = ring[0]
 
     def barrier():
         torch.cuda.synchronize()
@@ -107,10 +266,10 @@ def main():
         last = None
         for i in range(k):
             if len(streams) == 1:
-                last = pipe.restore(wav, n)
+                last = pipe.restore(ring[i % NRING], n)
             else:  # consecutive batches on alternating streams: one batch's GRU overlaps the other's convolutions
                 with torch.cuda.stream(streams[i % len(streams)]):
-                    last = pipe.restore(wav, n)
+                    last = pipe.restore(ring[i % NRING], n)
         return last
 
     out = run_steps(args.warmup)
@@ -133,6 +292,8 @@ def main():
             print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "events": False}), flush=True)
         return
     assert torch.isfinite(out).all()
+    pipe.check()  # device-side error flags (two-CU GRU hand-off)
+    last_idx = (args.steps - 1) % NRING  # ``out`` is the restoration of ring[last_idx]
 
     if dist is not None:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -227,22 +388,11 @@ def main():
             "rms_vs_f32": float(torch.sqrt(torch.mean((out3 - out) ** 2))),
             "note": "opt-in VoiceFixer.set_math('bf16x3'); parity bound 1e-3 RMS"}
 
+    if world == 1 and not args.no_host_leg:
+        line["host_to_host"] = host_to_host_leg(pipe, args, n, dev)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle  # checker/baseline only
-        vsd, rsd = weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321)
-        threads = torch.get_num_threads()
-        w1 = wav[0].cpu().numpy()
-        with torch.no_grad():
-            oracle.restore_inmem(w1[: 2 * SR], vsd, rsd)  # thread-pool / allocator warm-up (2 s)
-            c0 = time.perf_counter()
-            ref = oracle.restore_inmem(w1, vsd, rsd)
-            cdt = time.perf_counter() - c0
-        err = float(torch.sqrt(torch.mean((out[0].cpu() - torch.from_numpy(ref[0])) ** 2)))
-        line["cpu_baseline"] = {"value": round(args.seconds / cdt, 3), "unit": "x real-time", "cores": threads,
-                                "kind": "port",
-                                "sample": "1 utterance of %.0f s (utterance 0 of the batch), B=1 sequential like "
-                                          "voicefixer/__main__.py:187-212; %.1f s of CPU time" % (args.seconds, cdt),
-                                "rms_vs_gpu": err}
+        line["cpu_baseline"] = cpu_baseline(args, ring[last_idx][0].cpu().numpy(), out[0].cpu())
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -152,6 +152,13 @@ int vfx_avgpool2x2_f32(const vfx_tensor* x, const vfx_tensor* y, int B, int C, i
 int vfx_frontend_init(const float* window, const float* twiddle, const int32_t* lo,
                       const int32_t* hi, const int32_t* off, const float* coef, int nnz);
 
+/* Test hook: copy the banded filterbank the kernels read back to HOST buffers lo/hi/off[128], coef[coef_capacity]
+ * (which = 0: the HTK table of vfx_stft_mel_f32, 1: the slaney table of vfx_stft_mel_oracle_f32); *nnz_out = number
+ * of coefficients.  Lets a test assert the mel bin indexing bit-exactly on what the device holds (the reference's
+ * matrix is voicefixer/tools/mel_scale.py:147-238).  Tables are kept per device (the caller's current device). */
+int vfx_frontend_readback(int which, int32_t* lo, int32_t* hi, int32_t* off, float* coef, int coef_capacity,
+                          int* nnz_out);
+
 /* wav [B][N] (row stride wav_stride) -> mel [B][T][128], T = 1 + N/441.  Reflect-padded,
  * centred STFT (n_fft 2048, hop 441), |.| with the 1e-8 power clamp, banded HTK mel.
  * The 1025-bin spectrogram never leaves LDS.  N >= 1025.

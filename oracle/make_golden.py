@@ -16,6 +16,10 @@ Fixtures
                           (243, 729, 2187) exceed L1 = 7*106 = 742
   vocoder_B2_T24.npz      Vocoder.forward, batch 2, T even (pad_tail = 4)
   filterbank.npz          mel fb support (lo, hi per mel bin) + sha256 of the float32 bytes
+  mel_weight_table.npz    the 128-entry Config.mel_weight_torch table the reference holds
+                          (vocoder/config.py:161-290) and the constants (a, b) of its analytic fit
+                          (config.py:300-316): the reciprocal slaney area normalisation of librosa.filters.mel,
+                          used to pin oracle/librosa_like.mel_basis (python oracle/make_golden.py --constants)
 """
 import hashlib
 import os
@@ -44,7 +48,43 @@ def synth_wave(n, seed):
     return wav
 
 
+def write_reference_constants():
+    """Reference-held numeric tables (no model run): read straight from the imported reference Config."""
+    os.makedirs(OUT, exist_ok=True)
+    home = tempfile.mkdtemp(prefix="vfx_home_")
+    ref_shim.prepare_home(home)
+    ref_shim.import_reference(home)
+    from voicefixer.vocoder.config import Config
+    import inspect
+    table = Config.mel_weight_torch.numpy().astype(np.float64)
+    sig = inspect.signature(Config.get_mel_weight_torch)
+    a, b = float(sig.parameters["a"].default), float(sig.parameters["b"].default)
+    assert table.shape == (128,)
+    np.savez_compressed(os.path.join(OUT, "mel_weight_table.npz"), table=table, a=a, b=b)
+    print("mel_weight_table", table[0], table[-1], "fit a, b =", a, b)
+
+    # the restorer's HTK filterbank exactly as restorer/model.py:203 builds it
+    from voicefixer.tools.mel_scale import MelScale
+    fb = MelScale(n_mels=128, sample_rate=44100, n_stft=2048 // 2 + 1).fb
+    assert tuple(fb.shape) == (1025, 128) and fb.dtype == torch.float32
+    nz = fb > 0
+    lo = np.array([int(torch.nonzero(nz[:, m])[0]) for m in range(128)], dtype=np.int32)
+    hi = np.array([int(torch.nonzero(nz[:, m])[-1]) for m in range(128)], dtype=np.int32)
+    raw = fb.numpy().astype(np.float32)
+    sha = hashlib.sha256(raw.tobytes()).hexdigest()
+    # the same matrix with the sign of zeros dropped (fb[0, 0] is -0.0 in the reference: (-1 * 0) / f_diff; a banded
+    # table cannot and need not represent the sign of a zero OUTSIDE a band)
+    sha_abs = hashlib.sha256(np.abs(raw).tobytes()).hexdigest()
+    np.savez_compressed(os.path.join(OUT, "filterbank.npz"), lo=lo, hi=hi, nnz=int(nz.sum()), sha256=sha,
+                        sha256_abs=sha_abs, negative_zeros=int(np.signbit(raw).sum()))
+    print("fb nnz", int(nz.sum()), "sha256", sha, "sha256(|fb|)", sha_abs, "negative zeros", int(np.signbit(raw).sum()))
+
+
 def main():
+    if "--constants" in sys.argv[1:]:
+        write_reference_constants()
+        return
+    write_reference_constants()
     os.makedirs(OUT, exist_ok=True)
     home = tempfile.mkdtemp(prefix="vfx_home_")
     vsd = weights.seeded_vocoder_state(VOC_SEED)
@@ -93,15 +133,6 @@ def main():
     run_vocoder(mel, "vocoder_T101.npz")
     mel = 10 ** (torch.rand((2, 1, 24, 128), generator=g) * 5 - 2)
     run_vocoder(mel, "vocoder_B2_T24.npz")
-
-    fb = vf._model.mel.fb
-    nz = fb > 0
-    lo = np.array([int(torch.nonzero(nz[:, m])[0]) for m in range(128)], dtype=np.int32)
-    hi = np.array([int(torch.nonzero(nz[:, m])[-1]) for m in range(128)], dtype=np.int32)
-    sha = hashlib.sha256(fb.numpy().astype(np.float32).tobytes()).hexdigest()
-    np.savez_compressed(os.path.join(OUT, "filterbank.npz"), lo=lo, hi=hi, nnz=int(nz.sum()),
-                        sha256=sha)
-    print("fb nnz", int(nz.sum()), "sha256", sha)
 
 
 if __name__ == "__main__":

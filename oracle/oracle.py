@@ -340,44 +340,35 @@ def restore_inmem(wav, voc_sd, res_sd, dtype=torch.float32, vocoder_func=None):
     return torch.cat(res, -1).squeeze(0).numpy()
 
 
-def remove_higher_frequency(wav, ratio=0.95):
-    """voicefixer/base.py:87-104 with librosa.stft / librosa.istft (0.10.x defaults: n_fft 2048,
-    hop 512, periodic hann, center=True, pad_mode="constant") restated in numpy from their
-    published definitions -- librosa is not installed offline, so THIS function's parity against
-    the reference is unpinned.  Returns (filtered wav of length 512*(N//512), cut-off bin)."""
+def remove_higher_frequency(wav, ratio=0.95, stft_fn=None, istft_fn=None):
+    """voicefixer/base.py:87-104.  ``librosa.stft(wav)`` / ``librosa.istft(stft)`` (0.10.x defaults: n_fft 2048,
+    hop 512, periodic hann, center=True, pad_mode="constant") come from oracle/librosa_like.py, the numpy
+    restatement that tests/test_librosa_like.py pins against scipy.signal.stft/istft; ``stft_fn``/``istft_fn``
+    let that test substitute the scipy transforms for the whole function.  Everything between the two transforms
+    is the reference's own numpy code, line for line.  Returns (filtered wav of length 512*(N//512), cut-off bin)."""
+    from . import librosa_like
     EPS = 1e-8
     wav = np.asarray(wav, np.float32)
-    n_fft, hop = 2048, 512
-    x = np.pad(wav, (n_fft // 2, n_fft // 2), mode="constant")
-    win = (0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(n_fft) / n_fft)).astype(np.float32)
-    T = 1 + (len(x) - n_fft) // hop
-    idx = np.arange(n_fft)[None, :] + hop * np.arange(T)[:, None]
-    stft = np.fft.rfft(x[idx] * win[None, :], axis=1).T.astype(np.complex64)  # (1025, T)
+    stft = (stft_fn or (lambda y: librosa_like.stft(y, 512)))(wav)  # (1025, T) complex64
     real, img = np.real(stft), np.imag(stft)
     mag = (real ** 2 + img ** 2) ** 0.5
     cos, sin = real / (mag + EPS), img / (mag + EPS)
     spec = np.abs(stft)
-    feature = np.log10(spec.copy() + EPS)
+    feature = spec.copy()
+    feature = np.log10(feature + EPS)
     feature[feature < 0] = 0
     energy_level = np.sum(feature, axis=1)
     threshold = np.sum(energy_level) * ratio
     curent_level, i = energy_level[0], 0
+    # (the reference's loop condition `i < energy_level.shape[0]` would index energy_level[1025]; it cannot be
+    # reached for ratio < 1 because the running level equals the total at i = 1024)
     while i < energy_level.shape[0] - 1 and curent_level < threshold:
         curent_level += energy_level[i + 1, ...]
         i += 1
     spec[i:, ...] = np.zeros_like(spec[i:, ...])
     stft2 = spec * cos + 1j * spec * sin
-    # librosa.istft: irfft, window, overlap-add, window-sum-square normalisation, centre trim
-    frames = np.fft.irfft(stft2.T, n=n_fft, axis=1).astype(np.float32) * win[None, :]
-    total = n_fft + hop * (T - 1)
-    y = np.zeros(total, np.float32)
-    wss = np.zeros(total, np.float32)
-    for t in range(T):
-        y[t * hop: t * hop + n_fft] += frames[t]
-        wss[t * hop: t * hop + n_fft] += win ** 2
-    nz = wss > np.finfo(np.float32).tiny
-    y[nz] /= wss[nz]
-    return y[n_fft // 2: n_fft // 2 + hop * (T - 1)], i
+    y = (istft_fn or (lambda S: librosa_like.istft(S, 512)))(stft2)
+    return np.asarray(y, np.float32), i
 
 
 def to_int16(frames):

@@ -114,28 +114,6 @@ def test_int16_truncation_and_wav_roundtrip(tmp_path):
         audio_io.load_wav(str(tmp_path / "a.flac"))
 
 
-def test_oracle_frontend_length_identity():
-    """96 076 samples -> T = 218 -> T' = 222 -> 97 902 output samples (= the reference's oracle.flac)."""
-    from voicefixer_amd import oracle_frontend
-    g = torch.Generator().manual_seed(0)
-    c = oracle_frontend.wav_to_cond(torch.randn(96076, generator=g).numpy() * 0.1)
-    assert tuple(c.shape) == (1, 128, 222) and 441 * c.shape[-1] == 97902
-    assert c.min() >= -4.0 and c.max() <= 4.0 and (c[..., -4:] == -4.0).all()
-
-
-def test_oracle_mode1_prefilter_length_identity():
-    """132 300 samples -> 132 096 (= the reference's output_mode_1.flac length)."""
-    from oracle import oracle
-    g = torch.Generator().manual_seed(1)
-    t = np.arange(132300) / 44100.0
-    wav = (0.05 * torch.randn(132300, generator=g).numpy() + 0.3 * np.sin(2 * np.pi * 300 * t)).astype(np.float32)
-    y, cut = oracle.remove_higher_frequency(wav)
-    assert y.shape == (132096,) and 0 < cut <= 1024
-    # bins above the cut-off carry (almost) no energy afterwards
-    spec = np.abs(np.fft.rfft(y[4096:4096 + 2048] * np.hanning(2048)))
-    assert spec[min(cut + 8, 1024):].max() < 1e-3 * spec.max()
-
-
 def test_stream_chunk_plan():
     """Overlap-add planner: chunks every (chunk - overlap) samples, cover [0, n) exactly, short tails merged."""
     from voicefixer_amd.api import plan_stream_chunks

@@ -134,10 +134,11 @@ def test_vocoder_oracle_file(seeded_states, tmp_path):
     out = audio_io.load_wav(fout)
     T = 1 + 20000 // 441
     assert out.shape == (441 * (T + T % 2 + 4),)
-    # checker: the numpy restatement of the librosa front-end (oracle_frontend, host) + the CPU oracle generator
-    from voicefixer_amd import oracle_frontend
+    # checker: oracle/librosa_like.py (pinned against scipy + reference-held tables, tests/test_librosa_like.py)
+    # + the CPU oracle generator
+    from oracle import librosa_like
     with torch.no_grad():
-        cond_ref = oracle_frontend.wav_to_cond(audio_io.load_wav(fin))
+        cond_ref = librosa_like.wav_to_cond(audio_io.load_wav(fin))
         ref = oracle.vocoder_generator(cond_ref, seeded_states[0])
     want = oracle.to_int16((ref[0] * 2 ** 15).numpy())[0].astype(np.float32) / 32768.0
     assert np.abs(out - want).max() <= 2.5 / 32768.0
@@ -149,6 +150,141 @@ def test_vocoder_oracle_file(seeded_states, tmp_path):
     ops.mel_to_cond_plain(mel, cond, T2)
     torch.cuda.synchronize()
     assert (cond[:, :, : cond_ref.shape[-1]].cpu() - cond_ref).abs().max() < 2e-3  # dB domain: 20*log10 amplifies ulps near the 1e-5 floor
+
+
+def test_vocoder_oracle_baseline_config0(seeded_states, tmp_path):
+    """BASELINE configs[0]: Vocoder.oracle on a 2 s utterance of the fixture's length, N = 96 076 ->
+    T = 218, T' = 222 -> 97 902 samples (the length of the reference's test/utterance/target/oracle.flac);
+    a STEREO file: the reference vocodes the FIRST channel (vocoder/base.py:61), not a down-mix."""
+    voc = voicefixer_amd.Vocoder.from_state(seeded_states[0])
+    n = 96076
+    g = torch.Generator().manual_seed(96)
+    t = np.arange(n) / 44100.0
+    left = (0.05 * torch.randn(n, generator=g).numpy() + 0.3 * np.sin(2 * np.pi * 180 * t) * np.sin(2 * np.pi * 1.5 * t))
+    right = 0.5 * torch.randn(n, generator=g).numpy()
+    fin, fout = str(tmp_path / "stereo.wav"), str(tmp_path / "o.wav")
+    from scipy.io import wavfile
+    wavfile.write(fin, 44100, (np.stack([left, right], 1) * 32767 / 1.6).astype(np.int16))
+    voc.oracle(fin, fout, cuda=True)
+    out = audio_io.load_wav(fout)
+    assert out.shape == (97902,)
+    from oracle import librosa_like
+    first = audio_io.load_wav(fin, mono=False)[0]
+    with torch.no_grad():
+        ref = oracle.vocoder_generator(librosa_like.wav_to_cond(first), seeded_states[0])
+    want = oracle.to_int16((ref[0] * 2 ** 15).numpy())[0].astype(np.float32) / 32768.0
+    assert np.abs(out - want).max() <= 2.5 / 32768.0
+    assert _rms(out, want) < 1e-3                        # north-star bound (PCM16 quantisation included)
+
+
+def test_default_constructors_load_checkpoint_files(seeded_states, tmp_path, monkeypatch):
+    """VoiceFixer() / Vocoder(44100) through the DEFAULT constructors (voicefixer/base.py:15-30,
+    vocoder/base.py:24-32): checkpoints under ~/.cache/voicefixer, both weight-norm key styles, the
+    {"generator": ...} wrapper, a full restorer.model.VoiceFixer state dict with foreign keys to filter
+    (f_helper.*, mel.fb) and a ``vocoder.model.*`` override inside vf.ckpt -- bit-identical to from_state."""
+    from voicefixer_amd import weights
+    vsd, rsd = seeded_states
+    g = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    want = voicefixer_amd.VoiceFixer.from_state(vsd, rsd).restore_inmem(g["wav"], cuda=True)
+
+    def write_home(home, voc_state, ana_state):
+        a = os.path.join(home, ".cache/voicefixer/analysis_module/checkpoints")
+        v = os.path.join(home, ".cache/voicefixer/synthesis_module/44100")
+        os.makedirs(a)
+        os.makedirs(v)
+        torch.save({"generator": voc_state}, os.path.join(v, "model.ckpt-1490000_trimed.pt"))
+        torch.save(ana_state, os.path.join(a, "vf.ckpt"))
+
+    full = {"generator." + k: v for k, v in rsd.items()}
+    full["mel.fb"] = torch.zeros(1025, 128)
+    full["f_helper.stft.conv_real.weight"] = torch.zeros(1025, 1, 2048)
+    # (1) current key style, flat vf.ckpt
+    h1 = str(tmp_path / "h1")
+    write_home(h1, vsd, full)
+    monkeypatch.setenv("HOME", h1)
+    a = voicefixer_amd.VoiceFixer().restore_inmem(g["wav"], cuda=True)
+    assert np.array_equal(a, want)
+    voc = voicefixer_amd.Vocoder(44100)
+    gv = np.load(os.path.join(GOLDEN, "vocoder_B2_T24.npz"))
+    assert np.array_equal(voc.forward(torch.from_numpy(gv["mel"])).numpy(),
+                          voicefixer_amd.Vocoder.from_state(vsd).forward(torch.from_numpy(gv["mel"])).numpy())
+    # (2) legacy weight_g / weight_v keys in the vocoder file, Lightning-style {"state_dict": ...} vf.ckpt
+    h2 = str(tmp_path / "h2")
+    write_home(h2, weights.seeded_vocoder_state(1234, legacy=True), {"state_dict": full, "epoch": 3})
+    monkeypatch.setenv("HOME", h2)
+    b = voicefixer_amd.VoiceFixer().restore_inmem(g["wav"], cuda=True)
+    assert np.array_equal(b, want)
+    # (3) vf.ckpt carries vocoder.model.* keys: they override the synthesis-module file (SURVEY.md A.6) --
+    # a WRONG vocoder file plus the right weights inside vf.ckpt must still give the right answer
+    h3 = str(tmp_path / "h3")
+    over = dict(full)
+    over.update({"vocoder.model." + k: v for k, v in vsd.items()})
+    write_home(h3, weights.seeded_vocoder_state(999), over)
+    monkeypatch.setenv("HOME", h3)
+    c = voicefixer_amd.VoiceFixer().restore_inmem(g["wav"], cuda=True)
+    assert np.array_equal(c, want)
+    # ... and without the override the wrong file really is used
+    h4 = str(tmp_path / "h4")
+    write_home(h4, weights.seeded_vocoder_state(999), full)
+    monkeypatch.setenv("HOME", h4)
+    d = voicefixer_amd.VoiceFixer().restore_inmem(g["wav"], cuda=True)
+    assert not np.array_equal(d, want)
+    # missing files keep the reference's error strings
+    monkeypatch.setenv("HOME", str(tmp_path / "empty"))
+    with pytest.raises(RuntimeError, match="Error 0"):
+        voicefixer_amd.VoiceFixer()
+    with pytest.raises(RuntimeError, match="Error 1"):
+        voicefixer_amd.Vocoder(44100)
+
+
+def test_plugin_vocoder_shorter_than_segment(vf):
+    """_trim_center's other branch (base.py:71-76): an estimate SHORTER than the segment is returned as it is."""
+    gg = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    n = gg["wav"].shape[0]
+
+    def short(mel):
+        return torch.full((1, 1, n - 1000), 0.5)
+    c = vf.restore_inmem(gg["wav"], cuda=True, your_vocoder_func=short)
+    assert c.shape == (1, n - 1000) and np.all(c == 0.5)
+
+    def loud(mel):  # peak rule (base.py:131-133) on a short estimate
+        return torch.full((1, 1, n - 7), -2.0)
+    c = vf.restore_inmem(gg["wav"], cuda=True, your_vocoder_func=loud)
+    assert c.shape == (1, n - 7) and np.all(c == -1.0)
+
+
+def test_gru_error_flag_is_read_on_the_product_path(vf):
+    """The two-CU GRU's device flag (partner workgroup missed the bounded spin) must surface as VfxError on every
+    API that returns host data, and must be cleared afterwards."""
+    gg = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    pipe = vf._get_pipe()
+    vf.restore_inmem(gg["wav"], cuda=True)          # allocates the flag
+    assert int(pipe.restorer.gru_err.item()) == 0
+    pipe.restorer.gru_err.fill_(1)                   # simulate a timeout raised during the next call
+    with pytest.raises(_lib.VfxError, match="gru"):
+        vf.restore_inmem(gg["wav"], cuda=True)
+    assert int(pipe.restorer.gru_err.item()) == 0
+    pipe.restorer.gru_err.fill_(1)
+    with pytest.raises(_lib.VfxError):
+        vf.restore_batch([gg["wav"], gg["wav"][:9000]])
+    assert int(pipe.restorer.gru_err.item()) == 0
+    out = vf.restore_inmem(gg["wav"], cuda=True)     # healthy again
+    assert _rms(out, gg["restored"]) < 2e-5
+
+
+def test_four_streams_of_batch32_keep_the_gru_resident(vf):
+    """restore_batch's default: 4 streams; 8 buckets of 32 equal-length utterances -> four concurrent launch
+    sequences.  The GRU launches are sized per stream count (Pipeline.set_streams) so that every two-CU pair is
+    resident: the flag stays 0 and the results equal the single-stream ones bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    lens = [4410 + 441 * k for k in range(8)]
+    wavs = [(0.1 * torch.randn(n, generator=g)).numpy() for n in lens for _ in range(32)]
+    pipe = vf._get_pipe()
+    a = vf.restore_batch(wavs, batch_size=32, streams=4)
+    assert int(pipe.restorer.gru_err.item()) == 0
+    assert pipe.restorer.gru_group == 60             # back to the single-stream launch size
+    b = vf.restore_batch(wavs, batch_size=32, streams=1)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
 def test_mode1_matches_oracle(vf):
@@ -236,3 +372,29 @@ def test_restore_batch_multistream_bit_reproducible(vf):
                 assert all(np.array_equal(a, b) for a, b in zip(one, four)), math
         finally:
             vf.set_math("f32")
+
+
+def test_rccl_scatter_restore_gather_world1(vf, tmp_path):
+    """The multi-GPU job (BASELINE configs[3]) on the REAL backend: torch.distributed "nccl" (= RCCL) with
+    world_size 1 on this box's single GPU -- scatter_utterances / Pipeline.restore / gather_utterances run
+    through the RCCL code path (broadcast of the job size, device tensors) and return what a plain batched
+    restore returns.  (world_size 2 runs on gloo in tests/test_dist_cpu.py; the 8-GPU run is the driver's.)"""
+    import torch.distributed as dist
+    from voicefixer_amd import dist as vdist
+    pipe = vf._get_pipe()
+    n = 13230
+    g = torch.Generator().manual_seed(21)
+    wavs = (0.1 * torch.randn(5, n, generator=g)).cuda()
+    dist.init_process_group(backend="nccl", init_method="file://" + str(tmp_path / "rdzv"), world_size=1, rank=0,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        assert dist.get_backend() == "nccl"
+        timing = {}
+        out = vdist.restore_sharded(lambda w: pipe.restore(w, n), wavs, n, wavs.device, batch_size=2, timing=timing)
+        torch.cuda.synchronize()
+    finally:
+        dist.destroy_process_group()
+    assert tuple(out.shape) == (5, n) and set(timing) == {"scatter_s", "compute_s", "gather_s"}
+    want = torch.cat([pipe.restore(wavs[i:i + 2], n) for i in range(0, 5, 2)], 0)
+    assert torch.equal(out, want)
+    pipe.check()

@@ -50,6 +50,7 @@ SIGNATURES = {
     "vfx_conv1d_cout1_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _I, _I, _I, _I, _P]),
     "vfx_avgpool2x2_f32": (_I, [_T, _T, _I, _I, _I, _I, _P]),
     "vfx_frontend_init": (_I, [_P, _P, _P, _P, _P, _P, _I]),
+    "vfx_frontend_readback": (_I, [_I, _P, _P, _P, _P, _I, C.POINTER(_I)]),
     "vfx_stft_mel_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
     "vfx_frontend_init_oracle": (_I, [_P, _P, _P, _P, _I]),
     "vfx_peak_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),

@@ -130,7 +130,9 @@ class Vocoder(nn.Module):
         """wav file -> ground-truth mel (librosa-style STFT + slaney HTK mel) -> vocoder -> wav file
         (voicefixer/vocoder/base.py:58-77); only the file decode/encode runs on the host."""
         from . import ops
-        wav = audio_io.load_wav(fpath, self.rate, mono=True)
+        wav = audio_io.load_wav(fpath, self.rate, mono=False)
+        if wav.ndim == 2:
+            wav = np.ascontiguousarray(wav[0])  # read_wave(fpath)[..., 0]: the FIRST channel, not a down-mix (vocoder/base.py:61)
         eng = self._get_engine()
         w = torch.from_numpy(wav)[None].to(eng.device)
         N = w.shape[1]
@@ -235,8 +237,9 @@ class VoiceFixer(nn.Module):
         for a, b in tail:
             seg = torch.from_numpy(np.ascontiguousarray(wav[a:b]))[None].to(pipe.device)
             res.append(self._restore_segments(pipe, seg, b - a, mode, your_vocoder_func))
-        out = torch.cat(res, -1)
-        return out.cpu().numpy()
+        out = torch.cat(res, -1).cpu().numpy()  # (synchronises)
+        pipe.check()
+        return out
 
     @staticmethod
     def _restore_segments(pipe, seg, n, mode, your_vocoder_func):
@@ -261,6 +264,7 @@ class VoiceFixer(nn.Module):
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
         pool = [torch.cuda.Stream(device=pipe.device) for _ in range(max(1, int(streams)))]
+        pipe.set_streams(len(pool))
         main = torch.cuda.current_stream(pipe.device)
         for st in pool:
             st.wait_stream(main)
@@ -280,6 +284,8 @@ class VoiceFixer(nn.Module):
             i += len(grp)
             nb += 1
         torch.cuda.synchronize(pipe.device)
+        pipe.set_streams(1)
+        pipe.check()
         for grp, full in pending:
             full = full.cpu().numpy()
             for r, k in enumerate(grp):
@@ -312,6 +318,7 @@ class VoiceFixer(nn.Module):
             grp = [c for c in plan[i:i + batch_size] if c[1] == length]
             seg = torch.from_numpy(np.stack([wav[a:a + length] for a, _ in grp])).to(pipe.device)
             res = self._restore_segments(pipe, seg, length, mode, your_vocoder_func).cpu().numpy()
+            pipe.check()
             for (a, _), y in zip(grp, res):
                 y = y[None]
                 if a > 0:  # cross-fade with what the previous chunk left in the overlap

@@ -999,13 +999,16 @@ static const TileCfg kTiles[] = {
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-// Device-resident copies of tap tables, one per distinct geometry (a few dozen per model).
+// Device-resident copies of tap tables, one per (device, distinct geometry) (a few dozen per model).
 // First use of a geometry does a synchronous hipMalloc+hipMemcpy (warm-up); afterwards the
 // lookup is a host-side map hit, so steady-state launches stay asynchronous/capturable.
 static const ConvTables* device_tables(const ConvTables& tb) {
     static std::mutex mu;
     static std::map<std::string, const ConvTables*> cache;
-    std::string key(reinterpret_cast<const char*>(&tb), sizeof(tb));
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::string key(reinterpret_cast<const char*>(&dev), sizeof(dev));  // device memory: one copy per device
+    key.append(reinterpret_cast<const char*>(&tb), sizeof(tb));
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
@@ -1122,9 +1125,11 @@ static int fill_segments(ConvArgs& a, ConvTables& tb, int nphase, const PhaseSpe
 // split-K workspace: one growing device buffer per stream (allocated during warm-up; a launch that fits reuses it)
 static float* splitk_workspace(hipStream_t s, size_t bytes) {
     static std::mutex mu;
-    static std::map<hipStream_t, std::pair<float*, size_t>> pool;
+    static std::map<std::pair<int, hipStream_t>, std::pair<float*, size_t>> pool;  // (device, stream): the null stream exists per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lock(mu);
-    auto& e = pool[s];
+    auto& e = pool[std::make_pair(dev, s)];
     if (e.second < bytes) {
         if (e.first) hipFree(e.first);  // (waits for the launches that still use it)
         e.first = nullptr;

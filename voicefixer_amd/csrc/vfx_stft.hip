@@ -17,29 +17,73 @@
 #define NMEL 128
 #define FPW 4
 
-static float* d_window = nullptr;
-static float2* d_twiddle = nullptr;
-static int* d_lo = nullptr;
-static int* d_hi = nullptr;
-static int* d_off = nullptr;
-static float* d_coef = nullptr;
+// Device copies of the constant tables, one set PER DEVICE (a process may drive several GPUs; the normal
+// deployment is one process per GPU): indexed by the calling thread's current HIP device.
+#define VFX_MAX_DEVICES 64
+struct FrontTables {
+    float* window = nullptr;
+    float2* twiddle = nullptr;
+    int* lo = nullptr;     // HTK filterbank of the restorer front-end (vfx_frontend_init)
+    int* hi = nullptr;
+    int* off = nullptr;
+    float* coef = nullptr;
+    int nnz = 0;
+    int* olo = nullptr;    // slaney filterbank of the Vocoder.oracle front-end (vfx_frontend_init_oracle)
+    int* ohi = nullptr;
+    int* ooff = nullptr;
+    float* ocoef = nullptr;
+    int onnz = 0;
+};
+static FrontTables g_front[VFX_MAX_DEVICES];
+
+static FrontTables* front_tables() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VFX_MAX_DEVICES) return nullptr;
+    return &g_front[dev];
+}
+
+static hipError_t front_upload(void** dst, const void* src, size_t bytes) {
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+}
 
 extern "C" int vfx_frontend_init(const float* window, const float* twiddle, const int32_t* lo, const int32_t* hi,
                                  const int32_t* off, const float* coef, int nnz) {
     if (!window || !twiddle || !lo || !hi || !off || !coef || nnz <= 0) return VFX_EINVAL;
-    auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
-        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-        hipError_t e = hipMalloc(dst, bytes);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-    };
+    FrontTables* ft = front_tables();
+    if (!ft) return VFX_EINVAL;
     hipError_t e;
-    if ((e = up((void**)&d_window, window, NFFT * sizeof(float))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_twiddle, twiddle, (NFFT / 2) * sizeof(float2))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_lo, lo, NMEL * sizeof(int))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_hi, hi, NMEL * sizeof(int))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_off, off, NMEL * sizeof(int))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_coef, coef, (size_t)nnz * sizeof(float))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->window, window, NFFT * sizeof(float))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->twiddle, twiddle, (NFFT / 2) * sizeof(float2))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->lo, lo, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->hi, hi, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->off, off, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->coef, coef, (size_t)nnz * sizeof(float))) != hipSuccess) return (int)e;
+    ft->nnz = nnz;
+    return VFX_OK;
+}
+
+// Test hook: copy the banded filterbank the kernels actually read back to the host (which = 0: HTK table of
+// vfx_stft_mel_f32, 1: slaney table of vfx_stft_mel_oracle_f32).  coef holds up to coef_capacity floats.
+extern "C" int vfx_frontend_readback(int which, int32_t* lo, int32_t* hi, int32_t* off, float* coef, int coef_capacity,
+                                     int* nnz_out) {
+    FrontTables* ft = front_tables();
+    if (!ft || !lo || !hi || !off || !coef || !nnz_out || (which != 0 && which != 1)) return VFX_EINVAL;
+    const int* dlo = which ? ft->olo : ft->lo;
+    const int* dhi = which ? ft->ohi : ft->hi;
+    const int* doff = which ? ft->ooff : ft->off;
+    const float* dcoef = which ? ft->ocoef : ft->coef;
+    const int nnz = which ? ft->onnz : ft->nnz;
+    if (!dlo || nnz <= 0) return VFX_EINVAL;  // table not uploaded on this device
+    if (coef_capacity < nnz) return VFX_ERANGE;
+    hipError_t e;
+    if ((e = hipMemcpy(lo, dlo, NMEL * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+    if ((e = hipMemcpy(hi, dhi, NMEL * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+    if ((e = hipMemcpy(off, doff, NMEL * sizeof(int), hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+    if ((e = hipMemcpy(coef, dcoef, (size_t)nnz * sizeof(float), hipMemcpyDeviceToHost)) != hipSuccess) return (int)e;
+    *nnz_out = nnz;
     return VFX_OK;
 }
 
@@ -124,47 +168,41 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
 
 extern "C" int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int N, float* mel, vfx_stream_t stream) {
     if (!wav || !mel || B <= 0 || N < NFFT / 2 + 1 || B > 65535) return VFX_EINVAL;
-    if (!d_window) return VFX_EINVAL;  // vfx_frontend_init not called
+    const FrontTables* ft = front_tables();
+    if (!ft || !ft->window || !ft->lo) return VFX_EINVAL;  // vfx_frontend_init not called on this device
     const int T = 1 + N / HOP;
     dim3 grid((T + FPW - 1) / FPW, B);
     hipLaunchKernelGGL(stft_mel_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N,
-                       T, mel, (const uint32_t*)nullptr, d_window, d_twiddle, d_lo, d_hi, d_off, d_coef);
+                       T, mel, (const uint32_t*)nullptr, ft->window, ft->twiddle, ft->lo, ft->hi, ft->off, ft->coef);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
 
 // ---- Vocoder.oracle front-end (voicefixer/vocoder/base.py:61-71): wav / max|wav| -> |librosa.stft|
 // (hop 441, zero padding) -> slaney-normalised HTK mel (librosa.filters.mel), tables uploaded once.
-static int* d_olo = nullptr;
-static int* d_ohi = nullptr;
-static int* d_ooff = nullptr;
-static float* d_ocoef = nullptr;
-
 extern "C" int vfx_frontend_init_oracle(const int32_t* lo, const int32_t* hi, const int32_t* off, const float* coef,
                                         int nnz) {
     if (!lo || !hi || !off || !coef || nnz <= 0) return VFX_EINVAL;
-    auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
-        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
-        hipError_t e = hipMalloc(dst, bytes);
-        if (e != hipSuccess) return e;
-        return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-    };
+    FrontTables* ft = front_tables();
+    if (!ft) return VFX_EINVAL;
     hipError_t e;
-    if ((e = up((void**)&d_olo, lo, NMEL * sizeof(int))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_ohi, hi, NMEL * sizeof(int))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_ooff, off, NMEL * sizeof(int))) != hipSuccess) return (int)e;
-    if ((e = up((void**)&d_ocoef, coef, (size_t)nnz * sizeof(float))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->olo, lo, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->ohi, hi, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->ooff, off, NMEL * sizeof(int))) != hipSuccess) return (int)e;
+    if ((e = front_upload((void**)&ft->ocoef, coef, (size_t)nnz * sizeof(float))) != hipSuccess) return (int)e;
+    ft->onnz = nnz;
     return VFX_OK;
 }
 
 extern "C" int vfx_stft_mel_oracle_f32(const float* wav, int64_t wav_stride, int B, int N, const uint32_t* peak,
                                        float* mel, vfx_stream_t stream) {
     if (!wav || !mel || !peak || B <= 0 || N < 1 || B > 65535) return VFX_EINVAL;
-    if (!d_window || !d_olo) return VFX_EINVAL;  // vfx_frontend_init / vfx_frontend_init_oracle not called
+    const FrontTables* ft = front_tables();
+    if (!ft || !ft->window || !ft->olo) return VFX_EINVAL;  // vfx_frontend_init / vfx_frontend_init_oracle not called
     const int T = 1 + N / HOP;
     dim3 grid((T + FPW - 1) / FPW, B);
     hipLaunchKernelGGL(stft_mel_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N, T,
-                       mel, peak, d_window, d_twiddle, d_olo, d_ohi, d_ooff, d_ocoef);
+                       mel, peak, ft->window, ft->twiddle, ft->olo, ft->ohi, ft->ooff, ft->ocoef);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -231,12 +269,14 @@ __global__ __launch_bounds__(256) void hf_energy_kernel(const float2* __restrict
     const int f = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
     if (f > NFFT / 2) return;
     const float2* p = S + (long long)b * T * (NFFT / 2 + 1) + f;
-    float acc = 0.f;
+    // float64 running sum, rounded once: within 1 ulp of the reference's pairwise float32 np.sum(feature, axis=1)
+    // whatever T is (a sequential float32 sum drifts by ~T ulp, enough to move a borderline cut-off bin)
+    double acc = 0.0;
     for (int t = 0; t < T; ++t) {
         const float2 c = p[(long long)t * (NFFT / 2 + 1)];
-        acc += fmaxf(log10f(sqrtf(c.x * c.x + c.y * c.y) + 1e-8f), 0.f);
+        acc += (double)fmaxf(log10f(sqrtf(c.x * c.x + c.y * c.y) + 1e-8f), 0.f);
     }
-    E[b * (NFFT / 2 + 1) + f] = acc;
+    E[b * (NFFT / 2 + 1) + f] = (float)acc;
 }
 
 // the reference's while loop (base.py:97-101), one thread per utterance
@@ -244,8 +284,11 @@ __global__ void hf_cutoff_kernel(const float* __restrict__ E, float ratio, int* 
     const int b = blockIdx.x;
     if (threadIdx.x != 0) return;
     const float* e = E + b * (NFFT / 2 + 1);
-    float total = 0.f;
-    for (int f = 0; f <= NFFT / 2; ++f) total += e[f];
+    // np.sum(energy_level) is a pairwise float32 sum: a float64 sum rounded once is its nearest stand-in; the
+    // running level stays float32 like the reference's `curent_level += energy_level[i + 1]`
+    double tot = 0.0;
+    for (int f = 0; f <= NFFT / 2; ++f) tot += (double)e[f];
+    const float total = (float)tot;
     const float threshold = total * ratio;
     float level = e[0];
     int i = 0;
@@ -318,7 +361,10 @@ extern "C" int vfx_hf_cut_f32(const float* wav, int64_t wav_stride, int B, int N
                               float ratio, void* workspace, size_t workspace_bytes, int32_t* cutoff_out,
                               vfx_stream_t stream) {
     if (!wav || !out || !workspace || B <= 0 || N < HF_HOP || B > 65535) return VFX_EINVAL;
-    if (!d_window) return VFX_EINVAL;  // vfx_frontend_init not called
+    const FrontTables* ft = front_tables();
+    if (!ft || !ft->window) return VFX_EINVAL;  // vfx_frontend_init not called on this device
+    const float* d_window = ft->window;
+    const float2* d_twiddle = ft->twiddle;
     if (workspace_bytes < vfx_hf_workspace_bytes(B, N)) return VFX_ERANGE;
     if (!vfx_aligned16(workspace)) return VFX_EALIGN;
     const int T = 1 + N / HF_HOP;

@@ -64,10 +64,27 @@ def gather_utterances(mine, n_utt, n_samples, device, group=None, root=0):
     return None
 
 
-def restore_sharded(restore_fn, wavs_on_root, n_samples, device, batch_size=32, group=None, root=0):
+def restore_sharded(restore_fn, wavs_on_root, n_samples, device, batch_size=32, group=None, root=0, timing=None):
     """scatter -> each rank runs ``restore_fn(batch (b, n_samples)) -> (b, n_samples)`` over its block
-    in batches of ``batch_size`` -> gather on ``root``.  ``restore_fn`` is Pipeline.restore on GPUs."""
+    in batches of ``batch_size`` -> gather on ``root``.  ``restore_fn`` is Pipeline.restore on GPUs.
+    ``timing`` (optional dict) receives this rank's ``scatter_s`` / ``compute_s`` / ``gather_s`` wall times (each
+    phase ends with a device synchronise when the tensors live on a GPU)."""
+    import time
+
+    def sync():
+        if timing is not None and torch.device(device).type == "cuda":
+            torch.cuda.synchronize(device)
+
+    t0 = time.perf_counter()
     mine, _, n_utt = scatter_utterances(wavs_on_root, n_samples, device, group, root)
+    sync()
+    t1 = time.perf_counter()
     outs = [restore_fn(mine[i:i + batch_size]) for i in range(0, mine.shape[0], batch_size)]
     local = torch.cat(outs, 0) if outs else mine
-    return gather_utterances(local, n_utt, n_samples, device, group, root)
+    sync()
+    t2 = time.perf_counter()
+    out = gather_utterances(local, n_utt, n_samples, device, group, root)
+    sync()
+    if timing is not None:
+        timing.update(scatter_s=t1 - t0, compute_s=t2 - t1, gather_s=time.perf_counter() - t2)
+    return out

@@ -254,6 +254,9 @@ class RestorerEngine:
         self.act_sigmoid = ops.Act(post=POST_SIGMOID)
         self.gru_err = None   # device flag: set by vfx_gru_bidir2_f32 if a partner workgroup timed out
         self._gru_keep = []
+        # utterances per two-CU GRU launch (4 workgroups of 512 threads each, one per CU): a launch must be able
+        # to become resident next to the launches of the caller's other streams (Pipeline.set_streams)
+        self.gru_group = ops.GRU2_MAX_B
 
         self.enc = []
         for b in range(1, 7):
@@ -293,8 +296,8 @@ class RestorerEngine:
                 y = _rows(B, 512, T, G_TILE, dev)
                 # two CUs per sequence (W_hh resident in registers) while all 4*B workgroups fit on the
                 # chip; larger batches are walked in resident-sized groups
-                for b0 in range(0, B, ops.GRU2_MAX_B):
-                    b1 = min(B, b0 + ops.GRU2_MAX_B)
+                for b0 in range(0, B, self.gru_group):
+                    b1 = min(B, b0 + self.gru_group)
                     yv = y[b0:b1]
                     yv._vfx_guard = getattr(y, "_vfx_guard", 0)
                     keep.append(ops.gru_bidir2(gi[b0:b1], whh_t, bhh, yv, T, self.gru_err))
@@ -396,6 +399,22 @@ class Pipeline:
         self.restorer.set_math(math)
         self.math = math
 
+    def set_streams(self, streams):
+        """Tell the engine how many HIP streams issue ``restore`` concurrently: the two-CU GRU keeps one workgroup
+        per CU resident, so its launches are sized to 256 CUs / (4 workgroups per utterance x streams)."""
+        self.restorer.gru_group = max(1, min(ops.GRU2_MAX_B, 256 // (4 * max(1, int(streams)))))
+
+    def check(self):
+        """Read the device-side error flags (ONE 4-byte D2H copy; call it where the result crosses to the host,
+        i.e. where the API synchronises anyway).  The two-CU GRU raises its flag when a partner workgroup did not
+        answer within the bounded spin (vfx_gru.hip); the frames after that point were never written, so the
+        waveform must not be returned."""
+        flag = self.restorer.gru_err
+        if flag is not None and int(flag.item()) != 0:
+            flag.zero_()
+            raise VfxError("vfx_gru_bidir2_f32: a partner workgroup missed the bounded hand-off spin "
+                           "(GRU output incomplete); the result of this call was discarded")
+
     def wav_to_mel(self, wav, N):
         B = wav.shape[0]
         T = 1 + N // 441
@@ -418,9 +437,10 @@ class Pipeline:
             y = vocoder_func(den[:, None])  # plugin hook: (B,1,T,128) -> (B,1,samples)
             y = y.to(wav.device).float().contiguous()[:, 0]
             Ly = y.shape[-1]
-            if Ly < N:
-                raise VfxError("your_vocoder_func returned %d samples for a %d-sample segment" % (Ly, N))
-        out = torch.empty((B, N), device=wav.device)
+        # _trim_center (base.py:63-76): an estimate LONGER than the segment is centre-cropped to N samples; a
+        # SHORTER one (only a foreign your_vocoder_func can produce it) is returned as it is, Ly samples
+        n_out = min(N, Ly)
+        out = torch.empty((B, n_out), device=wav.device)
         ws = torch.empty((B,), dtype=torch.int32, device=wav.device)
-        ops.post(y, Ly, out, N, ws)
+        ops.post(y, Ly, out, n_out, ws)
         return out

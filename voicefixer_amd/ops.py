@@ -183,22 +183,32 @@ def avgpool2x2(x, y, H, pitch_log2):
           "vfx_avgpool2x2_f32")
 
 
-_frontend_ready = False
+_frontend_ready = set()   # device indices whose tables are uploaded (the library keeps one copy per device)
 
 
 def frontend_init():
     """Upload window / twiddles / banded HTK filterbank (voicefixer/tools/mel_scale.py:147-238
     restated in float32 torch with the same op order, so the support set is bit-identical)."""
-    global _frontend_ready
-    if _frontend_ready:
+    dev = torch.cuda.current_device()
+    if dev in _frontend_ready:
         return
-    import math
     from .frontend_tables import tables
     win, tw, lo, hi, off, coef = tables()
     check(_lib.lib().vfx_frontend_init(win.ctypes.data, tw.ctypes.data, lo.ctypes.data, hi.ctypes.data,
                                        off.ctypes.data, coef.ctypes.data, int(coef.shape[0])),
           "vfx_frontend_init")
-    _frontend_ready = True
+    _frontend_ready.add(dev)
+
+
+def frontend_readback(which=0):
+    """Test hook: the banded filterbank as it sits in device memory (0: HTK / restorer, 1: slaney / Vocoder.oracle)."""
+    import numpy as np
+    lo, hi, off = (np.zeros(128, np.int32) for _ in range(3))
+    coef = np.zeros(8192, np.float32)
+    nnz = C.c_int(0)
+    check(_lib.lib().vfx_frontend_readback(which, lo.ctypes.data, hi.ctypes.data, off.ctypes.data, coef.ctypes.data,
+                                           int(coef.shape[0]), C.byref(nnz)), "vfx_frontend_readback")
+    return lo, hi, off, coef[:nnz.value].copy()
 
 
 def stft_mel(wav, mel, N):
@@ -215,21 +225,19 @@ def stft_mel(wav, mel, N):
         PROFILE.append((-1, wav.shape[0] * (4 * N + 512 * (1 + N // 441)), e0, e1))
 
 
-_oracle_ready = False
+_oracle_ready = set()
 
 
 def oracle_mel(wav, N):
     """Vocoder.oracle front-end on the device: wav (B, >=N) -> slaney mel (B, T, 128) of wav/max|wav|."""
-    global _oracle_ready
     _need_cuda(wav)
     frontend_init()
-    if not _oracle_ready:
-        from .frontend_tables import banded
-        from .oracle_frontend import mel_basis
-        lo, hi, off, coef = banded(torch.from_numpy(mel_basis().T.copy()))
+    if torch.cuda.current_device() not in _oracle_ready:
+        from .frontend_tables import oracle_tables
+        lo, hi, off, coef = oracle_tables()
         check(_lib.lib().vfx_frontend_init_oracle(lo.ctypes.data, hi.ctypes.data, off.ctypes.data, coef.ctypes.data,
                                                   int(coef.shape[0])), "vfx_frontend_init_oracle")
-        _oracle_ready = True
+        _oracle_ready.add(torch.cuda.current_device())
     B = wav.shape[0]
     T = 1 + N // 441
     peak = torch.empty((B,), dtype=torch.int32, device=wav.device)
@@ -299,7 +307,7 @@ def gru_bidir(gi, whh_t, bhh, out, T):
           "vfx_gru_bidir_f32")
 
 
-GRU2_MAX_B = 32  # 4 workgroups per utterance, all resident; 128 per launch so that two streams' launches still fit 256 CUs
+GRU2_MAX_B = 60  # C ABI limit: 4 workgroups per utterance, one per CU, all resident (engine.Pipeline.set_streams sizes launches per stream count)
 
 
 def gru_bidir2(gi, whh_t, bhh, out, T, err_flag):
