@@ -79,6 +79,12 @@ typedef struct {
     int math;               /* VFX_MATH_* */
     const void* w_x3;       /* VFX_MATH_BF16X3: the packed weights as bf16 (hi, lo) planes, layout
                                [slab][Cin/16][plane][k-half][Cout][8] (voicefixer_amd/packing.py::pack_x3) */
+    const float* w_direct;  /* optional (may be NULL): the same fp32 weights packed [slab][CinPad/8][Cout][8], the 8
+                               channels of a group in the order 0,2,4,6,1,3,5,7 (packing.py::pack_direct).  Lets 1-D
+                               launches with 2-3 taps, zero padding, a guard band and no BatchNorm pre-activation run
+                               on convw_kernel (weights read from L2 as MFMA A-operand vectors, activations staged
+                               16-32 channels deep); bit-identical results are NOT implied (other summation order
+                               within fp32 rounding).  Everything else, and small launches, use w_packed. */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0
@@ -109,6 +115,15 @@ int vfx_last_conv_tile(void);
 int vfx_conv1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias,
                    const vfx_tensor* res, const vfx_tensor* y, int B, int Cin, int Cout, int L,
                    int k, int dilation, int pad_mode, const vfx_act* act, vfx_stream_t stream);
+
+/* One whole ResStack layer, fused (voicefixer/vocoder/model/modules.py:592-609, one iteration of the loop):
+ *   y[b,n,l] = post( x[b,n,l] + bias2[n] + conv_k3_d1( lrelu_s( bias1 + conv_k3_dil( lrelu_s(x) ) ) )[b,n,l] )
+ * for C = 64 or 128 channels.  The intermediate tensor lives in LDS (one tile of BL columns per workgroup, BL-2
+ * outputs), never in HBM.  x needs a guard band >= dilation + BL + 8 (vfx_tensor.guard); y must NOT alias x (a tile
+ * reads the input columns of its neighbours).  Weights in the w_direct layout of vfx_act.  post_act as vfx_act.post_act. */
+int vfx_resblock_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
+                     const float* w2_direct, const float* bias2, int B, int C, int L, int dilation, float slope,
+                     int post_act, float post_slope, vfx_stream_t stream);
 
 /* ConvTranspose1d(Cin, Cout, kernel 2s, stride s, padding s/2 + s%2, output_padding s%2):
  * Lin -> s*Lin.  Polyphase: s phases x 2 taps.  w_packed = [2s][CinPad][Cout], slab k is

@@ -203,6 +203,156 @@ def test_bf16x3_falls_back_to_fp32_outside_its_coverage():
     _close(yd[:, :, :L], ref, 2e-5)
 
 
+# ---- second-generation kernel: weights as L2-resident A-operand vectors (vfx_act.w_direct), fused ResStack layer ----
+def _guarded_nan(t, guard):
+    """Device copy of (B,C,L) into a guarded view whose guard band (and tail pad) holds NaN."""
+    B, Cn, L = t.shape
+    v = ops.guarded(B, Cn, L, guard, DEV)
+    v._vfx_base.fill_(float("nan"))
+    v[:, :, :L] = t.to(DEV)
+    return v
+
+
+CONVW_CASES = [
+    # B, Cin, Cout, L, dil, pre, post, res   (k = 3; sized so that the launch has >= 384 workgroups -> convw_kernel)
+    (4, 128, 128, 16000, 1, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (4, 128, 128, 16001, 3, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (4, 256, 128, 15999, 9, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (4, 128, 128, 16002, 27, _lib.PRE_NONE, _lib.POST_NONE, True),
+    (4, 128, 128, 16000, 81, _lib.PRE_LRELU, _lib.POST_LRELU_SNAKE, True),
+    (4, 128, 256, 8000, 243, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (4, 128, 128, 16000, 729, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (4, 128, 128, 16000, 2187, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (8, 64, 64, 16000, 1, _lib.PRE_LRELU, _lib.POST_LRELU, True),      # 64 x 256 tile
+    (8, 64, 64, 16003, 27, _lib.PRE_LRELU, _lib.POST_NONE, False),
+    (8, 128, 64, 16000, 81, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (8, 64, 64, 16000, 2187, _lib.PRE_LRELU, _lib.POST_LRELU, True),
+    (64, 32, 128, 1006, 1, _lib.PRE_NONE, _lib.POST_ELU, False),       # condnet-like: many short rows, Cin = 32 (one chunk)
+]
+
+
+@pytest.mark.parametrize("case", CONVW_CASES)
+def test_conv1d_convw(case):
+    B, Cin, Cout, L, dil, pre, post, use_res = case
+    x = _rand((B, Cin, L), 61)
+    w = _rand((Cout, Cin, 3), 62, (Cin * 3) ** -0.5)
+    bias = _rand((Cout,), 63, 0.1)
+    res = _rand((B, Cout, L), 64) if use_res else None
+    ref = F.conv1d(_ref_act(x, pre, 0.01), w, bias, dilation=dil, padding=dil)
+    if use_res:
+        ref = ref + res
+    ref = _ref_post(ref, post, 0.2)
+    xd = _guarded_nan(x, dil + 264)
+    lp = (L + 67) // 4 * 4
+    yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+    rd = _padded(res, lp) if use_res else None
+    act = ops.Act(pre=pre, pre_slope=0.01, post=post, post_slope=0.2)
+    wp = packing.pack_conv1d(w)
+    before = _lib.lib().vfx_launch_count()
+    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, rd, wd=packing.pack_direct(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (51, 52, 54), "launch did not run on convw_kernel"
+    _close(yd[:, :, :L], ref, 2e-5)
+    assert torch.isnan(yd[:, :, L:]).all()
+    if use_res and post == _lib.POST_NONE:
+        # in-place residual update (the engine's pattern for the unfused stages)
+        rd2 = _padded(res, lp)
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), rd2, L, 3, dil, 0, act, rd2, wd=packing.pack_direct(wp).to(DEV))
+        torch.cuda.synchronize()
+        _close(rd2[:, :, :L], ref, 2e-5)
+
+
+@pytest.mark.parametrize("cfg", [(4, 256, 128, 5000, 3), (2, 512, 256, 2000, 7), (8, 128, 64, 6000, 3)])
+def test_convtr1d_convw(cfg):
+    B, Cin, Cout, Lin, s = cfg
+    x = _rand((B, Cin, Lin), 71)
+    w = _rand((Cin, Cout, 2 * s), 72, (2 * Cin) ** -0.5)
+    bias = _rand((Cout,), 73, 0.1)
+    ref = F.conv_transpose1d(x + torch.sin(x) * 0, w, bias, stride=s, padding=s // 2 + s % 2, output_padding=s % 2)
+    xd = _guarded_nan(x, 264)
+    Lo = Lin * s
+    yd = torch.full((B, Cout, (Lo + 67) // 4 * 4), float("nan"), device=DEV)
+    wp = packing.pack_convtr1d(w)
+    ops.convtr1d(xd, wp.to(DEV), bias.to(DEV), yd, Lin, s, None, wd=packing.pack_direct(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (51, 52, 54), "launch did not run on convw_kernel"
+    _close(yd[:, :, :Lo], ref, 2e-5)
+    assert torch.isnan(yd[:, :, Lo:]).all()
+
+
+def test_convw_small_launches_stay_on_the_first_kernel():
+    x = _rand((1, 128, 700), 81)
+    w = _rand((128, 128, 3), 82, 0.05)
+    xd = _guarded_nan(x, 300)
+    yd = torch.empty((1, 128, 700), device=DEV)
+    wp = packing.pack_conv1d(w)
+    ops.conv1d(xd, wp.to(DEV), None, yd, 700, 3, 1, 0, None, wd=packing.pack_direct(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 < 50
+    _close(yd, F.conv1d(x, w, padding=1), 2e-5)
+
+
+RESBLOCK_CASES = [
+    # B, C, L, dil, post
+    (3, 64, 20000, 1, _lib.POST_NONE),
+    (2, 64, 20001, 3, _lib.POST_NONE),
+    (2, 64, 9999, 9, _lib.POST_LRELU),
+    (2, 64, 20003, 27, _lib.POST_NONE),
+    (2, 64, 20000, 81, _lib.POST_NONE),
+    (2, 64, 20000, 243, _lib.POST_NONE),
+    (2, 64, 20000, 729, _lib.POST_LRELU_SNAKE),
+    (2, 64, 20000, 2187, _lib.POST_NONE),
+    (1, 64, 300, 2187, _lib.POST_NONE),        # dilation > L, single tile
+    (1, 64, 253, 1, _lib.POST_NONE),           # one tile minus one
+    (1, 64, 254, 1, _lib.POST_NONE),           # exactly one tile of 254 outputs
+    (1, 64, 255, 1, _lib.POST_NONE),
+    (1, 64, 1, 1, _lib.POST_NONE),
+    (2, 128, 9000, 1, _lib.POST_NONE),
+    (2, 128, 9001, 3, _lib.POST_LRELU),
+    (2, 128, 9000, 27, _lib.POST_NONE),
+    (2, 128, 9002, 81, _lib.POST_NONE),
+    (2, 128, 9000, 243, _lib.POST_NONE),
+    (2, 128, 9000, 2187, _lib.POST_LRELU_SNAKE),
+    (1, 128, 126, 9, _lib.POST_NONE),
+    (1, 128, 127, 9, _lib.POST_NONE),
+]
+
+
+@pytest.mark.parametrize("case", RESBLOCK_CASES)
+def test_resblock_fused(case):
+    """vfx_resblock_f32 = one iteration of ResStack.forward (vocoder/model/modules.py:592-609):
+    x + conv_k3_d1(lrelu(conv_k3_dil(lrelu(x)))) with the intermediate tile in LDS."""
+    B, Cn, L, dil, post = case
+    x = _rand((B, Cn, L), 91)
+    w1 = _rand((Cn, Cn, 3), 92, (Cn * 3) ** -0.5)
+    b1 = _rand((Cn,), 93, 0.1)
+    w2 = _rand((Cn, Cn, 3), 94, (Cn * 3) ** -0.5)
+    b2 = _rand((Cn,), 95, 0.1)
+    mid = F.conv1d(F.leaky_relu(x, 0.01), w1, b1, dilation=dil, padding=dil)
+    ref = x + F.conv1d(F.leaky_relu(mid, 0.01), w2, b2, padding=1)
+    ref = _ref_post(ref, post, 0.2)
+    xd = _guarded_nan(x, 2187 + 264)
+    yd = ops.guarded(B, Cn, L, 2187 + 264, DEV)
+    yd._vfx_base.fill_(float("nan"))
+    w1d = packing.pack_direct(packing.pack_conv1d(w1)).to(DEV)
+    w2d = packing.pack_direct(packing.pack_conv1d(w2)).to(DEV)
+    before = _lib.lib().vfx_launch_count()
+    ops.resblock(xd, yd, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (61, 62, 64)
+    _close(yd[:, :, :L], ref, 2e-5)
+    base = yd._vfx_base
+    g = yd._vfx_guard
+    assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()  # nothing written outside [0, L)
+    with pytest.raises(_lib.VfxError):
+        ops.resblock(xd, xd, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil)      # in place is refused
+    with pytest.raises(_lib.VfxError):
+        ops.resblock(xd[:, :32], yd[:, :32], w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil)   # C = 32 is not covered
+
+
+
 def test_linear_transposed_output():
     """Linear as conv k=1 with a frame-major output view (B,T,out) -- used for GRU x-projections."""
     B, T, Cin, Cout = 2, 101, 512, 1536

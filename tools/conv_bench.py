@@ -42,6 +42,23 @@ SHAPES = {
     "unet6": ("c2", 384, 384, 32, 2, 0),
     "unet6q": ("c2", 96, 384, 32, 2, 0),
     "gru_proj": ("c1", 512, 1536, 1001, 1, 1),
+    # what-if shapes (not in the model): long K at a fixed output tile count, to separate per-tile overhead from the loop
+    "k3072": ("c1", 1024, 256, 49294, 3, 1),
+    "k6144": ("c1", 2048, 256, 49294, 3, 1),
+    "k384": ("c1", 128, 256, 49294, 3, 1),
+    "k192": ("c1", 64, 256, 49294, 3, 1),
+    # fused ResStack layers (vfx_resblock_f32): (kind, C, C, L, 3, dil); FLOPs = both convolutions
+    "rb4_d1": ("rb", 64, 64, 443646, 3, 1),
+    "rb4_d9": ("rb", 64, 64, 443646, 3, 9),
+    "rb4_d27": ("rb", 64, 64, 443646, 3, 27),
+    "rb4_d81": ("rb", 64, 64, 443646, 3, 81),
+    "rb4_d243": ("rb", 64, 64, 443646, 3, 243),
+    "rb4_d2187": ("rb", 64, 64, 443646, 3, 2187),
+    "rb3_d1": ("rb", 128, 128, 147882, 3, 1),
+    "rb3_d27": ("rb", 128, 128, 147882, 3, 27),
+    "rb3_d81": ("rb", 128, 128, 147882, 3, 81),
+    "rb3_d243": ("rb", 128, 128, 147882, 3, 243),
+    "rb3_d2187": ("rb", 128, 128, 147882, 3, 2187),
 }
 
 
@@ -51,6 +68,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--x3", action="store_true", help="VFX_MATH_BF16X3 (guarded inputs, 1-D shapes only)")
+    ap.add_argument("--wd", action="store_true", help="offer the convw_kernel weight layout (vfx_act.w_direct)")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -68,8 +86,18 @@ def main():
             w3 = packing.pack_x3(wp).to(dev) if args.x3 else None
             bias = torch.zeros(cout, device=dev)
             pad = 1 if kind == "c1r" else 0
-            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3)
+            wd = packing.pack_direct(wp).to(dev) if args.wd else None
+            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd)
             macs = B * L * cin * cout * k
+        elif kind == "rb":
+            x = ops.guarded(B, cin, L, 2187 + 264, dev)
+            x.normal_()
+            y = ops.guarded(B, cin, L, 2187 + 264, dev)
+            w1d = packing.pack_direct(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
+            w2d = packing.pack_direct(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
+            bias = torch.zeros(cout, device=dev)
+            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil)
+            macs = 2 * B * L * cin * cout * 3
         elif kind == "t1":
             s = k
             Lp = (L + 3) // 4 * 4
@@ -80,7 +108,8 @@ def main():
             w = wp.to(dev)
             w3 = packing.pack_x3(wp).to(dev) if args.x3 else None
             bias = torch.zeros(cout, device=dev)
-            fn = lambda: ops.convtr1d(x, w, bias, y, L, s, w3=w3)
+            wd = packing.pack_direct(wp).to(dev) if args.wd else None
+            fn = lambda: ops.convtr1d(x, w, bias, y, L, s, w3=w3, wd=wd)
             macs = B * L * cin * cout * 2 * s
         else:
             H, lp = L, k

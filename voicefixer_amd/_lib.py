@@ -25,7 +25,7 @@ class vfx_tensor(C.Structure):
 class vfx_act(C.Structure):
     _fields_ = [("pre_act", C.c_int), ("pre_slope", C.c_float), ("pre_scale", C.c_void_p),
                 ("pre_shift", C.c_void_p), ("post_act", C.c_int), ("post_slope", C.c_float),
-                ("math", C.c_int), ("w_x3", C.c_void_p)]
+                ("math", C.c_int), ("w_x3", C.c_void_p), ("w_direct", C.c_void_p)]
 
 
 PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU = 0, 1, 2
@@ -44,6 +44,7 @@ SIGNATURES = {
     "vfx_launch_count": (C.c_uint64, []),
     "vfx_last_conv_tile": (_I, []),
     "vfx_conv1d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _I, _A, _P]),
+    "vfx_resblock_f32": (_I, [_T, _T, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
     "vfx_convtr1d_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_conv2d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_convtr2d_3x3s2_f32": (_I, [_T, _P, _T, _I, _I, _I, _I, _I, _A, _P]),

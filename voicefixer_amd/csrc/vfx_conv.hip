@@ -104,6 +104,15 @@ struct ConvArgs {
     int buf3;               // bytes per LDS buffer (activation planes + weight tile)
     int bl3;                // output positions per tile (< BL when the halo is staged inside the BL columns)
     int xrow3, wrow3;       // ROWS == 3 (3x3 on a pitch map): byte step of one map row in x / of one kernel row in w3
+    // ---- convw_kernel (vfx_convw.inc): weights as L2-resident A-operand vectors, deep activation chunks
+    const float* wd;        // weights packed [slab][Cin/8][Cout][8 channels in the order 0,2,4,6,1,3,5,7]
+    int kcx;                // channels per activation chunk (8, 16 or 32)
+    int stagger, stagger_wgs;     // development: start stagger of the first residency round (s_sleep units, workgroups)
+    // fused ResStack layer: second convolution (k3, dilation 1) and the LDS tile between the two
+    const float* wd2;
+    const float* bias2;
+    int yp;                 // row pitch of the intermediate tile (floats)
+    float mid_slope;        // leaky-ReLU between the two convolutions
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -1145,6 +1154,8 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 // geometry is outside what conv_x3_kernel covers; the caller then runs the fp32 kernel.
 #define VFX_ENOTSUP (-100)
 
+#include "vfx_convw.inc"
+
 template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS = 1>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
@@ -1339,6 +1350,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     if (act && act->math == VFX_MATH_BF16X3) {
         const int rc3 = try_launch_x3(a, x, nphase, phs, act->w_x3, stream);
         if (rc3 != VFX_ENOTSUP) return rc3;
+    }
+    if (act && act->w_direct) {
+        const int rcw = try_launch_convw(a, x, nphase, phs, act->w_direct, stream);
+        if (rcw != VFX_ENOTSUP) return rcw;
     }
     // tile choice: maximise (tile efficiency) x (tail efficiency along L) x (wave quantisation)
     int best = -1;

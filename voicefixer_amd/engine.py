@@ -44,6 +44,19 @@ def _dev(t, device):
     return t.contiguous().float().to(device)
 
 
+def _wpair(w_packed, device):
+    """(w_packed, w_direct) on the device: the [slab][CinPad][Cout] layout of conv_taps_kernel and the
+    [slab][CinPad/8][Cout][8] A-operand layout of convw_kernel / vfx_resblock_f32 (packing.pack_direct)."""
+    return _dev(w_packed, device), _dev(packing.pack_direct(w_packed), device)
+
+
+import os as _os
+# development switches: VFX_FUSE=0 runs every ResStack layer as two launches, VFX_CONVW=0 (read by the library)
+# keeps every launch on the first-generation kernel
+_FUSE = _os.environ.get("VFX_FUSE", "1") != "0"
+FUSE_MAX_C = 128  # ResStack stages with at most this many channels run one fused launch per layer
+
+
 class VocoderEngine:
     """TFGAN-style 44.1 kHz generator: cond (B,128,T') -> wav (B,1,441*T')."""
 
@@ -60,19 +73,19 @@ class VocoderEngine:
         self.condnet = []
         for i in (0, 2, 4, 6, 8):
             p = "condnet.%d" % i
-            self.condnet.append((_dev(packing.pack_conv1d(wn(p)), device), _dev(sd[p + ".bias"], device)))
+            self.condnet.append(_wpair(packing.pack_conv1d(wn(p)), device) + (_dev(sd[p + ".bias"], device),))
         self.pre = (_dev(packing.pack_conv1d(wn("generator.1")), device), _dev(sd["generator.1.bias"], device))
         self.stages = []
         for j, s in enumerate(weights.UPSAMPLE_SCALES):
             up = "generator.%d.layer" % (3 + 3 * j)
             rs = "generator.%d" % (4 + 3 * j)
-            upw = (_dev(packing.pack_convtr1d(wn(up)), device), _dev(sd[up + ".bias"], device))
+            upw = _wpair(packing.pack_convtr1d(wn(up)), device) + (_dev(sd[up + ".bias"], device),)
             layers = []
             for i in range(weights.RESSTACK_DEPTH):
                 a = "%s.layers.%d.1" % (rs, i)
                 b = "%s.layers.%d.3" % (rs, i)
-                layers.append((_dev(packing.pack_conv1d(wn(a)), device), _dev(sd[a + ".bias"], device),
-                               _dev(packing.pack_conv1d(wn(b)), device), _dev(sd[b + ".bias"], device)))
+                layers.append(_wpair(packing.pack_conv1d(wn(a)), device) + (_dev(sd[a + ".bias"], device),) +
+                              _wpair(packing.pack_conv1d(wn(b)), device) + (_dev(sd[b + ".bias"], device),))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -107,9 +120,9 @@ class VocoderEngine:
         a = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev)
         b = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev)
         x = cond
-        for i, (w, bias) in enumerate(self.condnet):
+        for i, (w, wd, bias) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
-            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w))
+            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w), wd=wd)
             x = y
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
@@ -122,16 +135,27 @@ class VocoderEngine:
         for j, (s, upw, layers) in enumerate(self.stages):
             Lo = L * s
             c //= 2
+            fused = _FUSE and self.math == "f32" and c <= FUSE_MAX_C
             xs = _rows(B, c, Lo, G_DIL, dev)
-            ys = _rows(B, c, Lo, G_TILE, dev)
-            ops.convtr1d(h, upw[0], upw[1], xs, L, s, self.act_none, w3=self._x3(upw[0]))
+            ys = _rows(B, c, Lo, G_DIL if fused else G_TILE, dev)
+            ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
-            for i, (w1, b1, w2, b2) in enumerate(layers):
-                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1))
+            for i, (w1, w1d, b1, w2, w2d, b2) in enumerate(layers):
                 last = i == len(layers) - 1
+                if fused:
+                    # one launch per layer, intermediate tile in LDS; input and output ping-pong between xs and ys
+                    # (a tile reads its neighbours' input columns, so the update cannot be in place)
+                    post, pslope = POST_NONE, 0.0
+                    if last:
+                        post, pslope = (POST_LRELU if j == nst - 1 else POST_LRELU_SNAKE), 0.2
+                    src, dst = (xs, ys) if i % 2 == 0 else (ys, xs)
+                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope)
+                    continue
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d)
                 act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
-                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2))  # residual updated in place
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d)  # residual updated in place
+            assert len(layers) % 2 == 0  # the fused ping-pong ends in xs
             h = xs
             L = Lo
             del ys

@@ -90,29 +90,31 @@ class Act:
 
 
 _NOACT = None
-_X3ACTS = {}
+_ACTVARIANTS = {}
 
 
-def _act(a, w3=None):
-    """vfx_act* for a launch; ``w3`` (packing.pack_x3 planes on the device) opts the launch into
-    VFX_MATH_BF16X3 (the library falls back to fp32 for geometries its bf16x3 kernel does not cover)."""
+def _act(a, w3=None, wd=None):
+    """vfx_act* for a launch.  ``w3`` (packing.pack_x3 planes on the device) opts the launch into VFX_MATH_BF16X3 (the
+    library falls back to fp32 for geometries its bf16x3 kernel does not cover); ``wd`` (packing.pack_direct on the
+    device) offers the fp32 launch the convw_kernel weight layout (vfx_act.w_direct; the library decides)."""
     global _NOACT
     if a is None:
         if _NOACT is None:
             _NOACT = Act()
         a = _NOACT
-    if w3 is None:
+    if w3 is None and wd is None:
         return C.byref(a.c)
-    key = (id(a), w3.data_ptr())
-    ent = _X3ACTS.get(key)
+    key = (id(a), w3.data_ptr() if w3 is not None else 0, wd.data_ptr() if wd is not None else 0)
+    ent = _ACTVARIANTS.get(key)
     if ent is None:
         c = vfx_act(a.c.pre_act, a.c.pre_slope, a.c.pre_scale, a.c.pre_shift, a.c.post_act, a.c.post_slope,
-                    MATH_BF16X3, w3.data_ptr())
-        ent = _X3ACTS[key] = (c, a, w3)  # keep the owners alive with the struct
+                    MATH_BF16X3 if w3 is not None else MATH_F32, w3.data_ptr() if w3 is not None else None,
+                    wd.data_ptr() if wd is not None else None)
+        ent = _ACTVARIANTS[key] = (c, a, w3, wd)  # keep the owners alive with the struct
     return C.byref(ent[0])
 
 
-def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None):
+def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None, wd=None):
     """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout]."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
@@ -122,19 +124,31 @@ def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=Non
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3), _stream())
+                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3, wd), _stream())
     check(rc, "vfx_conv1d_f32")
     _prof_end(e0, B * L * cin * cout * k)
 
 
-def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None):
+def resblock(x, y, w1d, b1, w2d, b2, L, dilation, slope=0.01, post=POST_NONE, post_slope=0.0):
+    """One fused ResStack layer (vfx_resblock_f32): x (B,C,>=L) guarded view -> y (B,C,>=L), y must not alias x."""
+    _need_cuda(x, y, w1d, b1, w2d, b2)
+    B, Cn = x.shape[0], x.shape[1]
+    xd, yd = tdesc(x), tdesc(y)
+    e0 = _prof_begin()
+    rc = _lib.lib().vfx_resblock_f32(C.byref(xd), C.byref(yd), _ptr(w1d), _ptr(b1), _ptr(w2d), _ptr(b2), B, Cn, L,
+                                     dilation, float(slope), post, float(post_slope), _stream())
+    check(rc, "vfx_resblock_f32")
+    _prof_end(e0, 2 * B * L * Cn * Cn * 3)
+
+
+def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None, wd=None):
     _need_cuda(x, w, y, bias)
     B, cin = x.shape[0], x.shape[1]
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
     e0 = _prof_begin()
     rc = _lib.lib().vfx_convtr1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(yd), B, cin, cout, Lin, stride,
-                                     _act(act, w3), _stream())
+                                     _act(act, w3, wd), _stream())
     check(rc, "vfx_convtr1d_f32")
     _prof_end(e0, B * Lin * cin * cout * 2 * stride)
 

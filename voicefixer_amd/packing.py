@@ -42,6 +42,16 @@ def pack_linear(w):
     return _pad_cin(w.t()[None])
 
 
+def pack_direct(w_packed):
+    """[slab][CinPad][Cout] -> [slab][CinPad/8][Cout][8] for convw_kernel (vfx_act.w_direct, vfx_resblock_f32): within
+    each group of 8 input channels the order is (0,2,4,6,1,3,5,7), so that the 16-byte vector at [..][m][4*hi:4*hi+4]
+    is the MFMA A operand of row m for the four consecutive k-steps k = 2*kk + hi of v_mfma_f32_32x32x2_f32."""
+    s, cp, co = w_packed.shape
+    assert cp % 8 == 0
+    w = w_packed.reshape(s, cp // 8, 8, co)[:, :, [0, 2, 4, 6, 1, 3, 5, 7], :]
+    return w.permute(0, 1, 3, 2).contiguous().float()
+
+
 def pack_cout1(w):
     """Conv weight (1, Cin, k[, 1]) -> [Cin][k]."""
     return w.reshape(w.shape[1], -1).contiguous().float()
