@@ -426,6 +426,47 @@ def test_conv2d_3x3_bn_lrelu_residual(cfg):
     assert (got[..., P - 1] == 0).all()  # pad column written as zero
 
 
+@pytest.mark.parametrize("cfg", [(4, 32, 32, 256, 7, True, True), (8, 8, 32, 256, 7, False, True), (12, 64, 64, 64, 6, True, False),
+                                 (24, 128, 128, 64, 5, True, True), (32, 64, 128, 64, 5, False, True),
+                                 (32, 384, 384, 64, 3, True, True)])
+def test_conv2d_3x3_convw(cfg):
+    """3x3 on a pitch map on convw_kernel (vfx_act.w_direct; three row segments per chunk): eval-BatchNorm pre-activation
+    or none (the two convolutions of a ConvBlockRes), residual, pad column NaN on input and written as zero."""
+    B, Cin, Cout, H, lp, affine, use_res = cfg
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 111)
+    w = _rand((Cout, Cin, 3, 3), 112, (Cin * 9) ** -0.5)
+    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(113))
+    shift = _rand((Cin,), 114, 0.3)
+    bias = _rand((Cout,), 116, 0.1)
+    res = _rand((B, Cout, H, P - 1), 115) if use_res else None
+    xin = _ref_act(x, _lib.PRE_AFFINE_LRELU, 0.01, scale, shift) if affine else x
+    ref = F.conv2d(xin, w, bias, padding=1)
+    if use_res:
+        ref = ref + res
+    ref = F.leaky_relu(ref, 0.01) if affine else ref
+    G = P + 1 + 264
+    xd = ops.guarded(B, Cin, H * P, G, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xd[:, :, :H * P] = _to_pitch(x, lp).to(DEV)
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    rd = torch.nan_to_num(_to_pitch(res, lp).to(DEV), nan=0.0) if use_res else None
+    act = (ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=scale.to(DEV), shift=shift.to(DEV),
+                   post=_lib.POST_LRELU, post_slope=0.01) if affine else None)
+    wp = packing.pack_conv2d(w)
+    ops.conv2d(xd, wp.to(DEV), bias.to(DEV), yd, H, lp, 3, act, rd, wd=packing.pack_direct(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 59, "launch did not run on convw_kernel"
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 2e-5)
+    assert (got[..., P - 1] == 0).all()  # pad column written as zero
+    if use_res:  # in-place residual (the engine's ConvBlockRes pattern: out aliases the residual)
+        rd2 = rd.clone()
+        ops.conv2d(xd, wp.to(DEV), bias.to(DEV), rd2, H, lp, 3, act, rd2, wd=packing.pack_direct(wp).to(DEV))
+        torch.cuda.synchronize()
+        _close(_from_pitch(rd2, H, lp)[..., : P - 1], ref, 2e-5)
+
+
 @pytest.mark.parametrize("cfg", [(2, 32, 32, 64, 7, True, True), (1, 64, 64, 48, 6, True, False),
                                  (2, 128, 128, 16, 5, False, True), (1, 384, 384, 8, 3, True, True),
                                  (1, 768, 384, 8, 3, False, False), (1, 64, 128, 32, 5, True, False)])

@@ -116,11 +116,15 @@ def main():
             P = 1 << lp
             x = torch.randn((B, cin, H * P), device=dev)
             y = torch.empty((B, cout, H * P), device=dev)
-            w = packing.pack_conv2d(torch.randn((cout, cin, 3, 3), generator=g) * (cin * 9) ** -0.5).to(dev)
+            x = ops.guarded(B, cin, H * P, P + 1 + 264, dev)
+            x.normal_()
+            wp = packing.pack_conv2d(torch.randn((cout, cin, 3, 3), generator=g) * (cin * 9) ** -0.5)
+            w = wp.to(dev)
+            wd = packing.pack_direct(wp).to(dev) if args.wd else None
             sc = torch.ones(cin, device=dev)
             sh = torch.zeros(cin, device=dev)
             a2 = ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=sc, shift=sh)
-            fn = lambda: ops.conv2d(x, w, None, y, H, lp, 3, a2)
+            fn = lambda: ops.conv2d(x, w, None, y, H, lp, 3, a2, wd=wd)
             macs = B * H * (P - 1) * cin * cout * 9
         fn()
         torch.cuda.synchronize()

@@ -32,7 +32,7 @@ def hbm(fetch_csv, write_csv, out):
     w, nw = read(write_csv)
     res = {}
     for k in f:
-        if k not in w or "conv_taps" not in k and "gru" not in k and "stft" not in k:
+        if k not in w or not any(t in k for t in ("conv_taps", "convw", "gru", "stft", "conv_cout1")):
             continue
         fa = f[k]["FETCH_SIZE"] / nf[k]
         wa = w[k]["WRITE_SIZE"] / nw[k]
@@ -52,7 +52,7 @@ def mfma(m_csv, out):
     m, n = read(m_csv)
     res = {}
     for k, c in m.items():
-        if "conv_taps" not in k and "gru" not in k and "stft" not in k:
+        if not any(t in k for t in ("conv_taps", "convw", "gru", "stft", "conv_cout1")):
             continue
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         if gui <= 0:

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Take the profile set of one round on the GPU box (run through gpurun from the repo root):
+#   bash tools/profile_round.sh r02 [extra bench args]
+# Writes gpurun_out/prof_<tag>/: rocprofv3 kernel-trace stats of the bench command, three separate PMC passes
+# (FETCH_SIZE / WRITE_SIZE / matrix-pipe counters; the guide asks for separate --pmc passes, gpurun refuses mixed trace
+# domains) reduced by tools/pmc_summary.py, and the bench lines printed under the profiler.
+TAG=${1:-rXX}; shift
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+BENCH="python $PWD/bench.py --batch 32 --no-cpu-baseline --no-bf16x3 --no-host-leg $*"
+cd /tmp
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o r -- $BENCH --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc -o fetch -- $BENCH --steps 1 --warmup 1 > /dev/null 2> $OUT/fetch.log
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc -o write -- $BENCH --steps 1 --warmup 1 > /dev/null 2> $OUT/write.log
+rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/pmc -o m -- $BENCH --steps 1 --warmup 1 > /dev/null 2> $OUT/m.log
+cd - > /dev/null
+F=$(find $OUT/pmc -name "fetch_counter_collection.csv" | head -1); W=$(find $OUT/pmc -name "write_counter_collection.csv" | head -1); M=$(find $OUT/pmc -name "m_counter_collection.csv" | head -1)
+python tools/pmc_summary.py hbm "$F" "$W" $OUT/pmc_hbm_traffic.json
+python tools/pmc_summary.py mfma "$M" $OUT/pmc_mfma_util.json
+S=$(find $OUT/stats -name "r_kernel_stats.csv" | head -1); cp "$S" $OUT/kernel_stats.csv
+# keep the merge-back small: raw counter CSVs are large
+rm -rf $OUT/pmc $OUT/stats
+ls -la $OUT

@@ -1354,7 +1354,16 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         if (rc3 != VFX_ENOTSUP) return rc3;
     }
     if (act && act->w_direct) {
-        const int rcw = try_launch_convw(a, x, nphase, phs, act->w_direct, stream);
+        int rcw = VFX_ENOTSUP;
+        if (nphase == 1 && phs[0].ntaps == 9 && in_mask > 0) {
+            // 3x3 on a pitch map: taps (ky-1)*P + (kx-1), slab ky*3+kx
+            const int P = in_mask + 1;
+            bool ok = true;
+            for (int t = 0; t < 9; ++t) ok &= phs[0].taps[t].off == (t / 3 - 1) * P + (t % 3 - 1) && phs[0].taps[t].slab == t;
+            if (ok) rcw = try_launch_convw_2d(a, x, P, act->w_direct, stream);
+        } else {
+            rcw = try_launch_convw(a, x, nphase, phs, act->w_direct, stream);
+        }
         if (rcw != VFX_ENOTSUP) return rcw;
     }
     // tile choice: maximise (tile efficiency) x (tail efficiency along L) x (wave quantisation)

@@ -187,9 +187,9 @@ class _ConvBlock:
             sh1 = torch.cat([sh1, torch.zeros(extra)])
             self.cin = pad_cin
         self.cout = w1.shape[0]
-        self.w1 = _dev(packing.pack_conv2d(w1), device)
+        self.w1, self.w1d = _wpair(packing.pack_conv2d(w1), device)
         self.b1 = _dev(sh2, device)
-        self.w2 = _dev(packing.pack_conv2d(sd[p + ".conv2.weight"]), device)
+        self.w2, self.w2d = _wpair(packing.pack_conv2d(sd[p + ".conv2.weight"]), device)
         self.act1 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.01, scale=_dev(s1, device), shift=_dev(sh1, device),
                             post=POST_LRELU, post_slope=0.01)
         self.shortcut = None
@@ -218,8 +218,8 @@ class _ConvBlock:
             res = out
         else:
             res = x
-        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0])
-        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1])
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d)
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d)
 
 
 class RestorerEngine:
