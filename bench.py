@@ -300,8 +300,30 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    # ---- roofline bookkeeping for the dominant conv_taps_kernel instance (this rank) ----
-    by_tile = {}
+    # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
+    # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
+    # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 16: conv_x3_kernel,
+    # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
+    # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
+    import re
+
+    def family(tile):
+        bm, bl, code = tile // 100000, tile // 100 % 1000, tile % 100
+        if code in (51, 52, 54):
+            return ("w1d", bm, bl), "convw_kernel<%d,%d,*,*,NT=2|3,*,false>" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, [23], \d+, false>" % (bm, bl)
+        if code == 59:
+            return ("w2d", bm, bl), "convw_kernel<%d,%d,*,*,NT=9,*,false>" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, 9, \d+, false>" % (bm, bl)
+        if code in (61, 62, 64):
+            return ("wfused", bm, bl), "convw_kernel<%d,%d,*,*,3,*,true> (fused ResStack layer)" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, true>" % (bm, bl)
+        if code == 16:
+            return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
+        return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
+               r"conv_taps_kernel<%d, %d, \d+, \d+, %d," % (bm, bl, code)
+
+    by_fam = {}
     stft_bytes, stft_secs, stft_n = 0, 0.0, 0
     for tile, macs, e0, e1 in prof:
         if tile == -1:  # the STFT->mel front-end: `macs` carries its algorithmic bytes
@@ -309,29 +331,27 @@ def main():
             stft_secs += e0.elapsed_time(e1) * 1e-3
             stft_n += 1
             continue
-        d = by_tile.setdefault(tile, [0, 0, 0.0])
+        key, name, rx = family(tile)
+        d = by_fam.setdefault(key, [0, 0, 0.0, name, rx])
         d[0] += 1
         d[1] += macs
         d[2] += e0.elapsed_time(e1) * 1e-3
-    conv_time = sum(d[2] for d in by_tile.values())
-    conv_macs = sum(d[1] for d in by_tile.values())
-    dom = max(by_tile.items(), key=lambda kv: kv[1][2])
-    tile, (launches, macs, secs) = dom
+    conv_time = sum(d[2] for d in by_fam.values())
+    conv_macs = sum(d[1] for d in by_fam.values())
+    launches, macs, secs, kname, krx = max(by_fam.values(), key=lambda d: d[2])
     achieved = 2.0 * macs / secs / 1e12
-    # HBM bytes per launch of that kernel: PMC counters cannot be read live; they come from the committed
-    # rocprofv3 --pmc passes over this same command (profiles/r01_pmc_hbm_traffic_bench_b32.json)
+    # HBM bytes per launch of that family: PMC counters cannot be read live; they come from the committed rocprofv3
+    # --pmc passes over this same command (tools/profile_round.sh -> profiles/r02_pmc_hbm_traffic_bench_b32.json)
     traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_bench_b32.json")
+    tfile = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_bench_b32.json")
     if os.path.exists(tfile) and args.batch == 32 and abs(args.seconds - 10.0) < 1e-9:
-        # the instance family <BM, BL, WGM, WGL, KC, interior, *>: launch-weighted mean over its staging-slot variants
-        want = "conv_taps_kernel<%d, %d," % (tile // 100000, tile // 100 % 1000)
         num = den = 0
-        for kname, rec in json.load(open(tfile))["kernels"].items():
-            if want in kname and ", %d, true" % (tile % 100) in kname:
+        for kn, rec in json.load(open(tfile))["kernels"].items():
+            if re.search(krx, kn):
                 num += rec["hbm_bytes_per_launch"] * rec["launches"]
                 den += rec["launches"]
         traffic = int(num / den) if den else None
-    x3_dom = args.math == "bf16x3" and tile % 100 == 16
+    x3_dom = kname.startswith("conv_x3")
     # bf16x3 instance: three bf16 MFMA products per algorithmic product -> peak = dense bf16 peak / 3
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3_dom else FP32_MFMA_PEAK_TFLOPS
     if x3_dom:
@@ -339,13 +359,15 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic,
-        "kernel": ("conv_x3_kernel<BM=%d,BL=%d,KC=%d,*>" if x3_dom else "conv_taps_kernel<BM=%d,BL=%d,KC=%d,FAST,*>")
-                  % (tile // 100000, tile // 100 % 1000, tile % 100),
+        "kernel": kname, "kernel_name_regex": krx,
         "launches_per_step": launches // args.steps,
         "avg_launch_ms": round(secs / launches * 1e3, 4),
         "algorithmic_gflop_per_launch": round(2.0 * macs / launches / 1e9, 3),
         "all_conv_kernels": {"achieved": round(2.0 * conv_macs / conv_time / 1e12, 2),
                              "time_share_of_step": round(conv_time / dt, 4) if world == 1 else None},
+        "families": {d[3]: {"launches_per_step": d[0] // args.steps, "ms_per_step": round(d[2] / args.steps * 1e3, 2),
+                            "tflops": round(2.0 * d[1] / d[2] / 1e12, 1)}
+                     for d in sorted(by_fam.values(), key=lambda d: -d[2])[:8]},
     }
 
     if stft_n:

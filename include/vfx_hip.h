@@ -96,10 +96,14 @@ int vfx_version(void);
  * proves the HIP path, not a fallback, produced a result). */
 uint64_t vfx_launch_count(void);
 
-/* Tile configuration chosen by the most recent conv-family launch of the calling thread,
- * encoded BM*100000 + BL*100 + KC, i.e. the template instance family
- * conv_taps_kernel<BM,BL,*,*,KC,...> a profiler will show (bench.py's roofline bookkeeping);
- * KC == 16 marks the bf16x3 instance conv_x3_kernel<BM,BL,...>. */
+/* Kernel family chosen by the most recent conv-family launch of the calling thread, encoded
+ * BM*100000 + BL*100 + code (bench.py's roofline bookkeeping maps it to the template instances a profiler shows):
+ *   code 4 / 8        conv_taps_kernel<BM,BL,*,*,KC=code,...>   (first-generation kernel: small launches, reflect
+ *                     padding, 1x1 / transposed 2-D convolutions, split-K)
+ *   code 16           conv_x3_kernel<BM,BL,...>                  (opt-in bf16x3 arithmetic)
+ *   code 51 / 52 / 54 convw_kernel<BM,BL,*,*,NT=2|3,*,false>     (1-D, activation chunks of 8 / 16 / 32 channels)
+ *   code 59           convw_kernel<BM,BL,*,*,NT=9,*,false>       (3x3 on a pitch map)
+ *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels) */
 int vfx_last_conv_tile(void);
 
 /* ---- convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------

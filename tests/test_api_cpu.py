@@ -131,3 +131,31 @@ def test_stream_chunk_plan():
     assert p[-1][0] + p[-1][1] == n and p[-1][1] > ov + 1024
     with pytest.raises(ValueError):
         plan_stream_chunks(10 ** 6, 2000, 1500)
+
+
+def test_pack_direct_layout():
+    """packing.pack_direct: [slab][CinPad][Cout] -> [slab][CinPad/8][Cout][8] with the 8 channels of a group in the
+    order (0,2,4,6,1,3,5,7): the 16-byte vector at [..][m][4*hi : 4*hi+4] is lane (m, hi)'s MFMA A operand of the
+    four consecutive k-steps k = 2*kk + hi (include/vfx_hip.h, vfx_act.w_direct)."""
+    from voicefixer_amd import packing
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn((16, 20, 3), generator=g)          # Cout, Cin (padded to 24), k
+    wp = packing.pack_conv1d(w)
+    wd = packing.pack_direct(wp)
+    assert tuple(wp.shape) == (3, 24, 16) and tuple(wd.shape) == (3, 3, 16, 8) and wd.is_contiguous()
+    for s in range(3):
+        for c8 in range(3):
+            for hi in range(2):
+                for kk in range(4):
+                    assert torch.equal(wd[s, c8, :, 4 * hi + kk], wp[s, 8 * c8 + 2 * kk + hi, :])
+    assert torch.equal(wd[:, 2, :, [2, 3, 6, 7]], torch.zeros(3, 16, 4))   # channels 20..23 are zero fill
+
+
+def test_wav_length_from_header(tmp_path):
+    """restore_folder sorts / windows the folder by the lengths in the WAV headers before decoding anything."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(0)
+    for sr, n in ((44100, 1000), (22050, 1001), (48000, 777), (16000, 1234)):
+        p = str(tmp_path / ("f%d.wav" % sr))
+        wavfile.write(p, sr, (rng.standard_normal((n, 2)) * 1000).astype(np.int16))
+        assert audio_io.wav_length(p) == len(audio_io.load_wav(p))

@@ -335,25 +335,32 @@ class VoiceFixer(nn.Module):
 
     def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
-        ``infolder`` -> same file name in ``outfolder``), batched: files are decoded / resampled / down-mixed
-        by a thread pool, bucketed by length, restored ``batch_size`` at a time, and encoded to PCM16 by the
-        same pool while the next batch computes.  Returns the list of file names written."""
+        ``infolder`` -> same file name in ``outfolder``), batched and pipelined: the lengths come from the WAV headers,
+        the length-sorted list is cut into windows of 8 batches, and while window k is restored on the device (exact-
+        length buckets of up to ``batch_size``) a thread pool decodes / resamples / down-mixes window k+1 and encodes
+        window k-1 to PCM16.  Host memory holds two windows at most.  Returns the list of file names written."""
         from concurrent.futures import ThreadPoolExecutor
         self._check_mode(mode)
         if mode != 0:
             raise NotImplementedError("restore_folder batches mode 0; use restore() per file for mode 1")
         files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] == ".wav")
         os.makedirs(outfolder, exist_ok=True)
+        paths = [os.path.join(infolder, f) for f in files]
         with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
-            wavs = list(pool.map(lambda f: audio_io.load_wav(os.path.join(infolder, f), 44100), files))
-            writes = []
-            order = sorted(range(len(files)), key=lambda i: len(wavs[i]))
-            # one restore_batch call per window of the length-sorted list keeps host memory bounded and lets
-            # the encoder threads of window k overlap the device work of window k+1
+            # lengths from the headers only (cheap), so that the work list can be sorted and cut into windows before
+            # anything is decoded; then a three-stage pipeline over the windows of the length-sorted list:
+            #   decode / resample / down-mix window k+1 (pool)  ||  restore window k (device)  ||  encode window k-1 (pool)
+            lengths = list(pool.map(lambda p: audio_io.wav_length(p, 44100), paths))
+            order = sorted(range(len(files)), key=lambda i: lengths[i])
             win = max(batch_size, 1) * 8
-            for w0 in range(0, len(order), win):
-                idx = order[w0:w0 + win]
-                outs = self.restore_batch([wavs[i] for i in idx], your_vocoder_func, batch_size)
+            windows = [order[w0:w0 + win] for w0 in range(0, len(order), win)]
+            load = lambda i: audio_io.load_wav(paths[i], 44100)
+            writes = []
+            pending = [pool.submit(load, i) for i in windows[0]] if windows else []
+            for k, idx in enumerate(windows):
+                wavs = [f.result() for f in pending]
+                pending = [pool.submit(load, i) for i in windows[k + 1]] if k + 1 < len(windows) else []
+                outs = self.restore_batch(wavs, your_vocoder_func, batch_size)
                 for i, o in zip(idx, outs):
                     writes.append(pool.submit(audio_io.save_wave, o, os.path.join(outfolder, files[i]), 44100))
             for w in writes:

@@ -35,6 +35,19 @@ def save_wave(frames, fname, sample_rate=SR):
     wavfile.write(fname, sample_rate, pcm if pcm.shape[1] > 1 else pcm[:, 0])
 
 
+def wav_length(path, sample_rate=SR):
+    """Number of samples ``load_wav(path, sample_rate)`` will return, from the header alone (memory-mapped read)."""
+    from scipy.io import wavfile
+    sr, data = wavfile.read(path, mmap=True)
+    n = int(data.shape[0])
+    if sr == sample_rate:
+        return n
+    from math import gcd
+    g = gcd(int(sr), int(sample_rate))
+    up, down = sample_rate // g, sr // g
+    return -(-n * up // down)  # resample_poly: ceil(n * up / down)
+
+
 def load_wav(path, sample_rate=SR, mono=True):
     """Decode + (if needed) resample + downmix, float32 in [-1, 1] (librosa.load semantics)."""
     if not str(path).lower().endswith(".wav"):
