@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--no-bf16x3", action="store_true",
                     help="skip the auxiliary timing of the opt-in bf16x3 arithmetic (reported beside the fp32 headline)")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-to-host (PCIe inclusive) timing")
+    ap.add_argument("--graph", action="store_true",
+                    help="development (use with --no-events): replay a captured HIP graph per step (Pipeline.enable_graphs)")
     ap.add_argument("--scatter", action="store_true",
                     help="BASELINE configs[3]: rank 0 owns --utterances-per-gpu x N utterances, scatter/gather over RCCL")
     ap.add_argument("--utterances-per-gpu", type=int, default=256)
@@ -250,6 +252,8 @@ def main():
     pipe = engine.Pipeline(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321), dev, args.math)
     if args.scatter:
         return scatter_job(args, pipe, n, rank, world, dev, dist)
+    if args.graph:
+        pipe.enable_graphs(max_shapes=1, max_batch=args.batch)
     NRING = 3  # resident input batches; step i restores ring[i % NRING]
     ring = [synth_batch(args.batch, n, 1000 + 97 * k + rank, dev) for k in range(NRING)]
     wav = ring[0]

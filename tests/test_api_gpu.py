@@ -398,3 +398,29 @@ def test_rccl_scatter_restore_gather_world1(vf, tmp_path):
     want = torch.cat([pipe.restore(wavs[i:i + 2], n) for i in range(0, 5, 2)], 0)
     assert torch.equal(out, want)
     pipe.check()
+
+
+def test_hip_graph_replay_is_bit_identical(vf):
+    """Pipeline.enable_graphs: the ~300 launches of one (B, N) shape captured once and replayed -- same bits as the
+    eager path, for a repeated shape, a second shape, and after eviction (max_shapes = 1)."""
+    pipe = vf._get_pipe()
+    g = torch.Generator().manual_seed(31)
+    a = (0.1 * torch.randn(2, 12345, generator=g)).cuda()
+    b = (0.1 * torch.randn(1, 7000, generator=g)).cuda()
+    ea, eb = pipe.restore(a, 12345).clone(), pipe.restore(b, 7000).clone()
+    before = _lib.lib().vfx_launch_count()
+    pipe.enable_graphs(max_shapes=1, max_batch=2)
+    try:
+        r1 = pipe.restore(a, 12345)                  # capture (+ two eager warm-up passes) and first replay
+        n_capture = _lib.lib().vfx_launch_count() - before
+        r2 = pipe.restore(a * 1.0, 12345)            # pure replay: no new launches issued by the library
+        assert _lib.lib().vfx_launch_count() - before == n_capture
+        r3 = pipe.restore(b, 7000)                   # second shape evicts the first
+        r4 = pipe.restore(a, 12345)                  # re-captured
+        torch.cuda.synchronize()
+        assert torch.equal(r1, ea) and torch.equal(r2, ea) and torch.equal(r3, eb) and torch.equal(r4, ea)
+        big = (0.1 * torch.randn(3, 7000, generator=g)).cuda()   # above max_batch: eager
+        assert pipe.restore(big, 7000).shape == (3, 7000)
+    finally:
+        pipe.disable_graphs()
+    pipe.check()

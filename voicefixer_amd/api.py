@@ -195,6 +195,11 @@ class VoiceFixer(nn.Module):
         if self._pipe is not None:
             self._pipe.set_math(math)
 
+    def enable_graphs(self, max_shapes=4, max_batch=4):
+        """Extension: replay a captured HIP graph for repeated (batch <= max_batch, length) shapes (single utterances of
+        one length, the equal-length chunks of ``restore_stream``); bit-identical results, see engine.Pipeline."""
+        self._get_pipe().enable_graphs(max_shapes, max_batch)
+
     def _load_wav(self, path, sample_rate, threshold=0.95):
         return audio_io.load_wav(path, sample_rate)
 
