@@ -185,6 +185,12 @@ int vfx_frontend_readback(int which, int32_t* lo, int32_t* hi, int32_t* off, flo
 int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int N, float* mel,
                      vfx_stream_t stream);
 
+/* The same for rows of DIFFERENT sample counts n_rows[b] (device int32[B]) that share one frame count
+ * T = 1 + n_rows[b]/441: everything downstream of the mel (restorer, vocoder) depends on T only, so such utterances
+ * are batched exactly (folder driver: buckets by frame count instead of by sample count).  Pair with vfx_post_rows_f32. */
+int vfx_stft_mel_rows_f32(const float* wav, int64_t wav_stride, int B, const int32_t* n_rows, int T, float* mel,
+                          vfx_stream_t stream);
+
 /* Vocoder.oracle front-end on the device (voicefixer/vocoder/base.py:61-71): peak[b] = max|wav[b]|
  * (vfx_peak_f32, float bits in a uint32), then |librosa.stft(wav/peak)| (n_fft 2048, hop 441, zero
  * "constant" padding, no clamp) and the slaney-normalised HTK filterbank of librosa.filters.mel,
@@ -264,6 +270,11 @@ int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int 
  * peak_ws is a caller-provided device buffer of B uint32 words. */
 int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
                  int N, int B, uint32_t* peak_ws, vfx_stream_t stream);
+
+/* The same with per-row lengths: row b keeps n_rows[b] samples (device int32[B], every n_rows[b] <= n_max <= Ly),
+ * d = Ly - n_rows[b].  Columns >= n_rows[b] of out are left untouched. */
+int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
+                      const int32_t* n_rows, int n_max, int B, uint32_t* peak_ws, vfx_stream_t stream);
 
 #ifdef __cplusplus
 }

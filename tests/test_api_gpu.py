@@ -424,3 +424,35 @@ def test_hip_graph_replay_is_bit_identical(vf):
     finally:
         pipe.disable_graphs()
     pipe.check()
+
+
+def test_restore_batch_buckets_by_frame_count(vf):
+    """Utterances of different sample counts but one frame count (1 + n // 441) run as ONE batch with per-row lengths
+    in the STFT and the centre trim (vfx_stft_mel_rows_f32 / vfx_post_rows_f32); every row must equal the
+    restoration of that utterance alone bit for bit, and the CPU oracle within the parity tolerance."""
+    g = torch.Generator().manual_seed(41)
+    T = 37
+    lens = [441 * (T - 1), 441 * (T - 1) + 1, 441 * (T - 1) + 220, 441 * T - 1, 441 * (T - 1) + 220]   # all T = 37
+    lens += [441 * T, 441 * T + 5]                                                                   # T = 38
+    wavs = [(0.1 * torch.randn(n, generator=g)).numpy() for n in lens]
+    pipe = vf._get_pipe()
+    before = _lib.lib().vfx_launch_count()
+    outs = vf.restore_batch(wavs, batch_size=8, streams=2)
+    launches = _lib.lib().vfx_launch_count() - before
+    single = [vf.restore_inmem(w, cuda=True) for w in wavs]
+    per_utt = (_lib.lib().vfx_launch_count() - before - launches) / len(wavs)
+    assert launches < 2.5 * per_utt                      # two buckets, not seven
+    for w, o, s1 in zip(wavs, outs, single):
+        assert o.shape == (1, len(w)) and _rms(o, s1) < 2e-5      # (batch 5 and batch 1 pick different tile shapes)
+    # exactness of the per-row length handling: row r of the mixed batch == row 0 of a batch of the SAME size whose
+    # rows all have length n_r (same launch shapes, so bit for bit)
+    for r in (0, 1, 3):
+        same = torch.from_numpy(np.stack([wavs[r]] * 5)).cuda()
+        want = pipe.restore(same, lens[r])[0].cpu().numpy()
+        assert np.array_equal(outs[r][0], want)
+    with torch.no_grad():
+        ref = oracle.restore_inmem(wavs[2], *_states(vf))
+    assert _rms(outs[2], ref) < 2e-5
+    # the low-level entry refuses rows of different frame counts
+    with pytest.raises(_lib.VfxError):
+        pipe.restore_rows(torch.zeros((2, 441 * 40), device="cuda"), [441 * 36, 441 * 39])

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--math", default="f32")
+    ap.add_argument("--streams", default="1,2,4,8", help="comma-separated stream counts to time")
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     lens = rng.integers(5 * 44100, 10 * 44100, size=args.n)
@@ -27,7 +28,9 @@ def main():
     vf.set_math(args.math)
     vf.restore_batch(wavs[:4], streams=2)  # warm-up
     ref = None
-    for st in (1, 2, 4, 8):
+    frames = [1 + int(n) // 441 for n in lens]
+    print("%d utterances, %d distinct frame counts (= buckets of restore_batch)" % (args.n, len(set(frames))))
+    for st in [int(v) for v in args.streams.split(",")]:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         outs = vf.restore_batch(wavs, streams=st)

@@ -53,6 +53,8 @@ SIGNATURES = {
     "vfx_frontend_init": (_I, [_P, _P, _P, _P, _P, _P, _I]),
     "vfx_frontend_readback": (_I, [_I, _P, _P, _P, _P, _I, C.POINTER(_I)]),
     "vfx_stft_mel_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
+    "vfx_stft_mel_rows_f32": (_I, [_P, C.c_int64, _I, _P, _I, _P, _P]),
+    "vfx_post_rows_f32": (_I, [_P, C.c_int64, _I, _P, C.c_int64, _P, _I, _I, _P, _P]),
     "vfx_frontend_init_oracle": (_I, [_P, _P, _P, _P, _I]),
     "vfx_peak_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
     "vfx_stft_mel_oracle_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P, _P]),

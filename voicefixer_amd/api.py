@@ -260,11 +260,14 @@ class VoiceFixer(nn.Module):
     def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=4):
         """Batched folder inference (not in the reference, which loops files at B=1,
         voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i).
-        Utterances are bucketed by exact length (results are identical to restoring each alone); every bucket is
-        one batched launch sequence per 30 s segment index.  Buckets go round-robin to ``streams`` HIP streams:
-        with equal lengths the low-occupancy phases of one batch (GRU recurrence, deep UNet levels) overlap the
-        convolutions of the next (+5 %); with ragged lengths (every file its own bucket, B = 1) several utterances
-        run concurrently on a chip that a single one cannot fill."""
+        Utterances of up to 30 s are bucketed by FRAME COUNT T = 1 + n // 441: only the STFT's reflect padding and the
+        final centre trim see the sample count n (per-row lengths in those two kernels), everything between depends
+        on T alone, so a bucket is one batched launch sequence whose rows are identical to restoring each utterance
+        alone (a folder of 2048 files of 5-10 s has ~4 files per frame count; a small ragged folder still has mostly
+        single-file buckets).  Longer files (several 30 s segments) are bucketed by exact length, one batched launch
+        sequence per segment index.  Buckets go round-robin to ``streams`` HIP streams: the low-occupancy phases of one
+        bucket (GRU recurrence, deep UNet levels) overlap the convolutions of the next, and single-file buckets run
+        several at a time on a chip that one utterance cannot fill."""
         pipe = self._get_pipe()
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
@@ -273,28 +276,49 @@ class VoiceFixer(nn.Module):
         main = torch.cuda.current_stream(pipe.device)
         for st in pool:
             st.wait_stream(main)
+
+        def key(k):  # bucket key of utterance k
+            n = len(wavs[k])
+            if your_vocoder_func is None and 1025 <= n <= SEG_LENGTH:
+                return ("frames", 1 + n // 441)
+            return ("samples", n)
+
         pending = []
         i = 0
         nb = 0
         while i < len(order):
-            n = len(wavs[order[i]])
-            grp = [k for k in order[i:i + batch_size] if len(wavs[k]) == n]
+            kind, val = key(order[i])
+            grp = [k for k in order[i:i + batch_size] if key(k) == (kind, val)]
             with torch.cuda.stream(pool[nb % len(pool)]):
-                parts = []
-                for s0 in range(0, n, SEG_LENGTH):
-                    seg = np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH] for k in grp])
-                    parts.append(pipe.restore(torch.from_numpy(seg).to(pipe.device, non_blocking=False),
-                                              seg.shape[1], your_vocoder_func))
-                pending.append((grp, torch.cat(parts, -1)))
+                if kind == "frames":
+                    lens = [len(wavs[k]) for k in grp]
+                    if min(lens) == max(lens):
+                        seg = np.stack([np.asarray(wavs[k], np.float32) for k in grp])
+                        full = pipe.restore(torch.from_numpy(seg).to(pipe.device), lens[0], None)
+                    else:
+                        seg = np.zeros((len(grp), max(lens)), np.float32)
+                        for r, k in enumerate(grp):
+                            seg[r, :lens[r]] = np.asarray(wavs[k], np.float32)
+                        full = pipe.restore_rows(torch.from_numpy(seg).to(pipe.device), lens)
+                    pending.append((grp, lens, full))
+                else:
+                    n = val
+                    parts = []
+                    for s0 in range(0, n, SEG_LENGTH):
+                        seg = np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH] for k in grp])
+                        parts.append(pipe.restore(torch.from_numpy(seg).to(pipe.device, non_blocking=False),
+                                                  seg.shape[1], your_vocoder_func))
+                    full = torch.cat(parts, -1)
+                    pending.append((grp, [full.shape[-1]] * len(grp), full))
             i += len(grp)
             nb += 1
         torch.cuda.synchronize(pipe.device)
         pipe.set_streams(1)
         pipe.check()
-        for grp, full in pending:
+        for grp, lens, full in pending:
             full = full.cpu().numpy()
             for r, k in enumerate(grp):
-                outs[k] = full[r:r + 1]
+                outs[k] = full[r:r + 1, :lens[r]]
         return outs
 
     @torch.no_grad()

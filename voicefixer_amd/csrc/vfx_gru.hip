@@ -305,18 +305,21 @@ __global__ __launch_bounds__(512, 2) void gru2_kernel(const float* __restrict__ 
             } else {
                 const u64* src = my_box + slot + ju * 3;
                 float pv[3];
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    u64 v = 0;
-                    unsigned spins = 0;
-                    for (;;) {
-                        v = __hip_atomic_load(src + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((unsigned)(v >> 32) == tag) break;
-                        if (++spins > G2_SPIN_LIMIT) { failed = true; break; }
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    pv[q] = __uint_as_float((unsigned)v);
+                // the three granules are polled TOGETHER: three loads in flight per round trip to L2 instead of three
+                // dependent round trips (one per gate) -- the hand-off is the critical path of every time step
+                u64 v0 = 0, v1 = 0, v2 = 0;
+                unsigned spins = 0;
+                for (;;) {
+                    v0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag && (unsigned)(v2 >> 32) == tag) break;
+                    if (++spins > G2_SPIN_LIMIT) { failed = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
+                pv[0] = __uint_as_float((unsigned)v0);
+                pv[1] = __uint_as_float((unsigned)v1);
+                pv[2] = __uint_as_float((unsigned)v2);
                 ar += pv[0] + br;
                 az += pv[1] + bz;
                 an += pv[2] + bn;

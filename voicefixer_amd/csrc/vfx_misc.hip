@@ -295,11 +295,14 @@ __global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ y, 
     }
 }
 
-__global__ __launch_bounds__(256) void trim_kernel(const float* __restrict__ y, long long y_bs, int start,
-                                                   float* __restrict__ out, long long o_bs, int N,
-                                                   const uint32_t* __restrict__ peak) {
+__global__ __launch_bounds__(256) void trim_kernel(const float* __restrict__ y, long long y_bs, int start0,
+                                                   float* __restrict__ out, long long o_bs, int N0,
+                                                   const uint32_t* __restrict__ peak, const int* __restrict__ n_rows,
+                                                   int Ly) {
     const int b = blockIdx.y;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int N = n_rows ? n_rows[b] : N0;                 // per-utterance length (vfx_post_rows_f32)
+    const int start = n_rows ? (Ly - N) / 2 : start0;      // _trim_center: drop (Ly - N) // 2 samples in front
     if (i >= N) return;
     const float pk = __uint_as_float(peak[b]);
     float v = y[(long long)b * y_bs + start + i];
@@ -331,7 +334,24 @@ extern "C" int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* ou
     VFX_LAUNCHED();
     const int d = Ly - N;
     hipLaunchKernelGGL(trim_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, y, (long long)y_bstride, d / 2, out,
-                       (long long)out_bstride, N, peak_ws);
+                       (long long)out_bstride, N, peak_ws, (const int*)nullptr, Ly);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}
+
+// Per-row lengths: row b keeps n_rows[b] <= n_max <= Ly samples (device int32[B]); out rows are n_max apart at least.
+extern "C" int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
+                                 const int32_t* n_rows, int n_max, int B, uint32_t* peak_ws, vfx_stream_t stream) {
+    if (!y || !out || !peak_ws || !n_rows || B <= 0 || n_max <= 0 || Ly < n_max || B > 65535) return VFX_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(peak_ws, 0, sizeof(uint32_t) * B, s);
+    if (e != hipSuccess) return (int)e;
+    int nb = (Ly + 255) / 256;
+    if (nb > 256) nb = 256;
+    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws);
+    VFX_LAUNCHED();
+    hipLaunchKernelGGL(trim_kernel, dim3((n_max + 255) / 256, B), dim3(256), 0, s, y, (long long)y_bstride, 0, out,
+                       (long long)out_bstride, n_max, peak_ws, (const int*)n_rows, Ly);
     VFX_LAUNCHED();
     return vfx_last_error();
 }

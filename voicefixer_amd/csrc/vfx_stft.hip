@@ -88,8 +88,8 @@ extern "C" int vfx_frontend_readback(int which, int32_t* lo, int32_t* hi, int32_
 }
 
 template <bool ORACLE>
-__global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__ wav, long long wav_stride, int N,
-                                                       int T, float* __restrict__ mel,
+__global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__ wav, long long wav_stride, int N0,
+                                                       const int* __restrict__ n_rows, int T, float* __restrict__ mel,
                                                        const uint32_t* __restrict__ peak,
                                                        const float* __restrict__ window,
                                                        const float2* __restrict__ twiddle, const int* __restrict__ lo,
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const float* x = wav + (long long)b * wav_stride;
+    const int N = n_rows ? n_rows[b] : N0;   // per-utterance sample count (rows of one frame count T batched together)
 
     for (int i = tid; i < NFFT / 2; i += 256) tw[i] = twiddle[i];
 
@@ -173,7 +174,23 @@ extern "C" int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int
     const int T = 1 + N / HOP;
     dim3 grid((T + FPW - 1) / FPW, B);
     hipLaunchKernelGGL(stft_mel_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N,
-                       T, mel, (const uint32_t*)nullptr, ft->window, ft->twiddle, ft->lo, ft->hi, ft->off, ft->coef);
+                       (const int*)nullptr, T, mel, (const uint32_t*)nullptr, ft->window, ft->twiddle, ft->lo, ft->hi,
+                       ft->off, ft->coef);
+    VFX_LAUNCHED();
+    return vfx_last_error();
+}
+
+// The same for a batch whose rows have DIFFERENT sample counts but the same frame count T = 1 + n/441 (n_rows: device
+// int32[B], every n_rows[b] in [441*(T-1), 441*T) and >= 1025): everything downstream of the mel depends on T only.
+extern "C" int vfx_stft_mel_rows_f32(const float* wav, int64_t wav_stride, int B, const int32_t* n_rows, int T, float* mel,
+                                     vfx_stream_t stream) {
+    if (!wav || !mel || !n_rows || B <= 0 || T < 3 || B > 65535) return VFX_EINVAL;
+    const FrontTables* ft = front_tables();
+    if (!ft || !ft->window || !ft->lo) return VFX_EINVAL;
+    dim3 grid((T + FPW - 1) / FPW, B);
+    hipLaunchKernelGGL(stft_mel_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, 0,
+                       (const int*)n_rows, T, mel, (const uint32_t*)nullptr, ft->window, ft->twiddle, ft->lo, ft->hi, ft->off,
+                       ft->coef);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -201,8 +218,8 @@ extern "C" int vfx_stft_mel_oracle_f32(const float* wav, int64_t wav_stride, int
     if (!ft || !ft->window || !ft->olo) return VFX_EINVAL;  // vfx_frontend_init / vfx_frontend_init_oracle not called
     const int T = 1 + N / HOP;
     dim3 grid((T + FPW - 1) / FPW, B);
-    hipLaunchKernelGGL(stft_mel_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N, T,
-                       mel, peak, ft->window, ft->twiddle, ft->olo, ft->ohi, ft->ooff, ft->ocoef);
+    hipLaunchKernelGGL(stft_mel_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, wav, (long long)wav_stride, N,
+                       (const int*)nullptr, T, mel, peak, ft->window, ft->twiddle, ft->olo, ft->ohi, ft->ooff, ft->ocoef);
     VFX_LAUNCHED();
     return vfx_last_error();
 }

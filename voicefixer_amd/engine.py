@@ -495,6 +495,26 @@ class Pipeline:
             return static_out.clone()
         return self._restore_eager(wav, N, vocoder_func)
 
+    def restore_rows(self, wav, lengths):
+        """Utterances of DIFFERENT sample counts that share one frame count T = 1 + n // 441, as one batch:
+        wav device float32 (B, >= max(lengths)), lengths a list of ints.  Only the STFT (reflect padding at each row's
+        end) and the final centre trim see the sample count; restorer and vocoder depend on T alone, so every row
+        equals what ``restore`` returns for that utterance alone.  Returns device (B, max(lengths)); row b is valid up
+        to lengths[b] (zero beyond)."""
+        T = 1 + lengths[0] // 441
+        if any(1 + n // 441 != T for n in lengths) or min(lengths) < 1025:
+            raise VfxError("restore_rows needs rows of one frame count (1 + n // 441) and n >= 1025")
+        B, n_max = wav.shape[0], max(lengths)
+        n_rows = torch.tensor(lengths, dtype=torch.int32, device=wav.device)
+        mel = torch.empty((B, T, 128), device=wav.device)
+        ops.stft_mel_rows(wav, mel, n_rows, T)
+        _, den = self.restorer.forward(mel, T)
+        y, Ly = self.vocoder.forward(den, T)
+        out = torch.zeros((B, n_max), device=wav.device)
+        ws = torch.empty((B,), dtype=torch.int32, device=wav.device)
+        ops.post_rows(y[:, 0], Ly, out, n_rows, n_max, ws)
+        return out
+
     def _restore_eager(self, wav, N, vocoder_func=None):
         if N < 1025:
             raise VfxError("segment of %d samples is too short for the reflect-padded STFT (needs > 1024); "

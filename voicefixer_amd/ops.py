@@ -239,6 +239,15 @@ def stft_mel(wav, mel, N):
         PROFILE.append((-1, wav.shape[0] * (4 * N + 512 * (1 + N // 441)), e0, e1))
 
 
+def stft_mel_rows(wav, mel, n_rows, T):
+    """wav (B, >= max n) device float32, n_rows device int32 (B,) with 1 + n // 441 == T for every row -> mel (B, T, 128)."""
+    _need_cuda(wav, mel, n_rows)
+    frontend_init()
+    assert wav.stride(1) == 1 and mel.is_contiguous() and n_rows.dtype == torch.int32
+    check(_lib.lib().vfx_stft_mel_rows_f32(_ptr(wav), wav.stride(0), wav.shape[0], _ptr(n_rows), T, _ptr(mel), _stream()),
+          "vfx_stft_mel_rows_f32")
+
+
 _oracle_ready = set()
 
 
@@ -342,6 +351,13 @@ def mel_to_cond(mel, cond, T):
     assert mel.is_contiguous()
     cd = tdesc(cond)
     check(_lib.lib().vfx_mel_to_cond_f32(_ptr(mel), C.byref(cd), mel.shape[0], T, _stream()), "vfx_mel_to_cond_f32")
+
+
+def post_rows(y, Ly, out, n_rows, n_max, peak_ws):
+    """y (B, >=Ly) -> out (B, >= n_max): per-utterance peak rule + centre trim to n_rows[b] samples (device int32)."""
+    _need_cuda(y, out, peak_ws, n_rows)
+    check(_lib.lib().vfx_post_rows_f32(_ptr(y), y.stride(0), Ly, _ptr(out), out.stride(0), _ptr(n_rows), n_max,
+                                       y.shape[0], _ptr(peak_ws), _stream()), "vfx_post_rows_f32")
 
 
 def post(y, Ly, out, N, peak_ws):
