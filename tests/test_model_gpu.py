@@ -175,3 +175,27 @@ def test_batch32_full_size_properties(pipe):
     assert _rms(out[0].numpy(), alone_a[0].numpy()) < RMS_TOL
     assert _rms(out[17].numpy(), alone_b[0].numpy()) < RMS_TOL
     assert _rms(out[17].numpy(), out[0].numpy()) > 1e-3  # the two utterances really differ
+
+
+def test_batch32_every_row_against_the_oracle(pipe, seeded_states):
+    """Batch 32 compared with the CPU oracle DIRECTLY, every row its own utterance (the headline batch size runs the
+    convw / fused kernels on every stage; the 10 s rows of the bench are checked through properties above and, for
+    one row, by bench.py's rms_vs_gpu).  0.68 s utterances keep the 32 oracle runs within a minute."""
+    from oracle import oracle
+    vsd, rsd = seeded_states
+    n = 30000
+    g = torch.Generator().manual_seed(99)
+    t = torch.arange(n, dtype=torch.float32) / 44100.0
+    f0 = 100.0 + 15.0 * torch.arange(32, dtype=torch.float32)[:, None]
+    batch = 0.08 * torch.randn(32, n, generator=g) + 0.25 * torch.sin(2 * np.pi * f0 * t[None])
+    out = pipe.restore(batch.cuda(), n)
+    torch.cuda.synchronize()
+    pipe.check()
+    out = out.cpu().numpy()
+    worst = 0.0
+    with torch.no_grad():
+        for b in range(32):
+            ref = oracle.restore_inmem(batch[b].numpy(), vsd, rsd)
+            worst = max(worst, _rms(out[b], ref[0]))
+    assert worst < RMS_TOL, worst
+    assert worst < NORTH_STAR_RMS
