@@ -107,7 +107,7 @@ struct ConvArgs {
     // ---- convw_kernel (vfx_convw.inc): weights as L2-resident A-operand vectors, deep activation chunks
     const float* wd;        // weights packed [slab][Cin/8][Cout][8 channels in the order 0,2,4,6,1,3,5,7]
     int kcx;                // channels per activation chunk (8, 16 or 32)
-    int ntiles_l;                 // fused layer (with tpw = consecutive tiles per workgroup): tiles along L
+    int ntiles_l, xcd_chunk;      // tiles along L; XCD-aware tile order: tiles per XCD (0 = linear order)
     int stagger, stagger_wgs;     // development: start stagger of the first residency round (s_sleep units, workgroups)
     int w_tap0, w_tapstep, w_slab0, w_slabstep, w_slab_ph, w_ooff0, w_ooff_ph, w_nseg, w_seg0, w_segstep;  // tap geometry (affine)
     // fused ResStack layer: second convolution (k3, dilation 1) and the LDS tile between the two
