@@ -23,6 +23,7 @@
 // Accumulators start at bias (+ residual); interior tiles (guard bands) run a branch-free
 // instance, instantiated per number of activation staging slots.
 #include "vfx_common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -1023,6 +1024,15 @@ static const ConvTables* device_tables(const ConvTables& tb) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
+    {
+        static const bool dump = getenv("VFX_DEBUG_ARGS") && atoi(getenv("VFX_DEBUG_ARGS")) != 0;  // development
+        if (dump) {
+            fprintf(stderr, "conv table:");
+            const unsigned* w = reinterpret_cast<const unsigned*>(&tb);
+            for (size_t i = 0; i < sizeof(PhaseTab) / 4; ++i) fprintf(stderr, " %08x", w[i]);
+            fprintf(stderr, "\n");
+        }
+    }
     ConvTables* d = nullptr;
     if (hipMalloc((void**)&d, sizeof(ConvTables)) != hipSuccess) return nullptr;
     if (hipMemcpy(d, &tb, sizeof(ConvTables), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
@@ -1044,6 +1054,16 @@ static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
+    }
+    {
+        static const bool dump = getenv("VFX_DEBUG_ARGS") && atoi(getenv("VFX_DEBUG_ARGS")) != 0;  // development
+        if (dump) {
+            fprintf(stderr, "conv_taps<%d,%d,%d,%d,%d,%d,%d,%d> grid %u %u %u lds %zu args:", BM, BL, WGM, WGL, KC, (int)FAST,
+                    NXV, (int)SPLITK, grid.x, grid.y, grid.z, lds);
+            const unsigned* w = reinterpret_cast<const unsigned*>(&a);
+            for (size_t i = 0; i < sizeof(ConvArgs) / 4; ++i) fprintf(stderr, " %08x", w[i]);
+            fprintf(stderr, "\n");
+        }
     }
     hipLaunchKernelGGL(kern, grid, dim3(64 * WGM * WGL), lds, s, a);
     VFX_LAUNCHED();
