@@ -135,7 +135,10 @@ class VocoderEngine:
         for j, (s, upw, layers) in enumerate(self.stages):
             Lo = L * s
             c //= 2
-            fused = _FUSE and self.math == "f32" and c <= FUSE_MAX_C
+            # (the fused kernel addresses one batch item with 32-bit byte offsets: rows of more than ~3 minutes at the last
+            # stage fall back to the two-launch form, whose first-generation kernel has no such limit)
+            fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and
+                     c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
             xs = _rows(B, c, Lo, G_DIL, dev)
             ys = _rows(B, c, Lo, G_DIL if fused else G_TILE, dev)
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
