@@ -199,3 +199,23 @@ def test_batch32_every_row_against_the_oracle(pipe, seeded_states):
             worst = max(worst, _rms(out[b], ref[0]))
     assert worst < RMS_TOL, worst
     assert worst < NORTH_STAR_RMS
+
+
+def test_vocoder_four_minute_mel_falls_back_to_64bit_safe_kernels(pipe):
+    """Vocoder.forward on a 4-minute mel (T = 24 000: 10.6 M positions per channel at the last stage).  The fused layer
+    and convw_kernel address one batch item with 32-bit byte offsets; rows this long must fall back (engine: two-launch
+    layers, library: first-generation kernel) instead of wrapping around.  The vocoder is convolutional with a
+    receptive field of < 5 s, so the first minute must equal the run on the first 75 s alone."""
+    g = torch.Generator().manual_seed(5)
+    T = 24000
+    mel = (10 ** (torch.rand((1, T, 128), generator=g) * 3 - 2)).cuda()
+    voc = pipe.vocoder
+    long_wav, L = voc.forward(mel, T)
+    short_wav, Ls = voc.forward(mel[:, :7500].contiguous(), 7500)
+    torch.cuda.synchronize()
+    assert L == 441 * (T + 4) and torch.isfinite(long_wav[:, :, :L]).all()
+    n = 441 * 6000
+    a, b = long_wav[0, 0, :n].cpu().numpy(), short_wav[0, 0, :n].cpu().numpy()
+    assert _rms(a, b) < 1e-5
+    del long_wav, short_wav
+    torch.cuda.empty_cache()

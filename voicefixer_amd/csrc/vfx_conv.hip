@@ -1214,6 +1214,8 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     const int Cin = a.Cin, Cout = a.Cout, B = a.B, Lq = a.Lq, Lin = a.Lin;
     if (!w3 || !vfx_aligned16(w3) || Cin % 32 != 0 || Cout % 32 != 0) return VFX_ENOTSUP;
     if (a.pad_mode == VFX_PAD_REFLECT) return VFX_ENOTSUP;
+    // (raw buffer resource, 32-bit byte offsets within one batch item: see launch_conv)
+    if (((long long)a.CinPad * x->cstride + Lin + 2 * x->guard) * 4 >= (1ll << 31) - (1ll << 20)) return VFX_ENOTSUP;
     // 3x3 on a pitch map (9 taps (ky-1)*P + (kx-1), slab ky*3+kx) -> 3 kernel rows x the 3-tap dx case
     int rows = 1, P = 0;
     PhaseSpec row_spec;
@@ -1476,6 +1478,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         int thi = room >= 0 ? (int)(room / a.bl_step) + 1 : 0;
         if (thi > ntiles) thi = ntiles;
         if (tlo > thi || Cin % KC != 0) { tlo = 0; thi = 0; }
+        // the interior instance reads one batch item through a raw buffer resource with 32-bit byte offsets
+        // (num_records 2^31 - 1: anything beyond reads as zero): rows of a batch item spanning 2 GB or more (a
+        // 64-channel stage of > 3 minutes) run the general, pointer-addressed instance on every tile
+        if (((long long)a.CinPad * x->cstride + Lin + 2 * g) * 4 >= (1ll << 31) - (1ll << 20)) { tlo = 0; thi = 0; }
         a.tile_lo = tlo;
         a.tile_hi = thi;
         if (exact && !(tlo == 0 && thi == ntiles)) { exact = false; continue; }  // boundary tiles: aligned layout
