@@ -46,6 +46,11 @@ typedef struct {
                       arbitrary, they are masked) before l = 0 and after l = L-1 of every (b, c) row.
                       With a guard >= the largest tap offset + 8 every tile takes the branch-free
                       interior kernel; 0 is always legal (boundary tiles then run the general kernel). */
+    const int32_t* rows; /* ragged batches (may be NULL): device int32[B], the VALID length of batch item b of this
+                      tensor (<= the L / H*P argument of the call, which is then the row capacity).  As an INPUT of the
+                      conv family, positions >= rows[b] are zero padding of the activated input (reflect padding
+                      mirrors at rows[b]); outputs past a row's valid length are unspecified.  Lets utterances of
+                      different lengths share one launch with results identical to separate launches. */
 } vfx_tensor;
 
 /* pre-activation applied to the INPUT while it is staged into LDS */
@@ -185,9 +190,8 @@ int vfx_frontend_readback(int which, int32_t* lo, int32_t* hi, int32_t* off, flo
 int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int N, float* mel,
                      vfx_stream_t stream);
 
-/* The same for rows of DIFFERENT sample counts n_rows[b] (device int32[B]) that share one frame count
- * T = 1 + n_rows[b]/441: everything downstream of the mel (restorer, vocoder) depends on T only, so such utterances
- * are batched exactly (folder driver: buckets by frame count instead of by sample count).  Pair with vfx_post_rows_f32. */
+/* The same for rows of DIFFERENT sample counts n_rows[b] (device int32[B], each >= 1025): row b gets its own
+ * 1 + n_rows[b]/441 frames, T is the row pitch of mel (>= every row's frame count).  Pair with vfx_post_rows_f32. */
 int vfx_stft_mel_rows_f32(const float* wav, int64_t wav_stride, int B, const int32_t* n_rows, int T, float* mel,
                           vfx_stream_t stream);
 
@@ -264,6 +268,10 @@ int vfx_mel_to_cond_f32(const float* mel, const vfx_tensor* cond, int B, int T,
  * whose mel is already slaney-normalised: vocoder/base.py:72 has no weight division) */
 int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int T, int apply_weight,
                            vfx_stream_t stream);
+/* ragged batches: t_rows (device int32[B], may be NULL) = frames of every row, T = row pitch of mel; row b is written
+ * up to its own t_rows[b] + t_rows[b]%2 + 4 frames */
+int vfx_mel_to_cond_rows_f32(const float* mel, const vfx_tensor* cond, int B, int T, const int32_t* t_rows,
+                             int apply_weight, vfx_stream_t stream);
 
 /* Per-utterance peak rule + centre trim (voicefixer/base.py:131-135, _trim_center :63-76):
  * peak[b] = max|y[b,:]|; out[b, 0:N] = y[b, d/2 : d/2+N] * (peak>1 ? 1/peak : 1), d = Ly-N.
@@ -271,10 +279,12 @@ int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int 
 int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
                  int N, int B, uint32_t* peak_ws, vfx_stream_t stream);
 
-/* The same with per-row lengths: row b keeps n_rows[b] samples (device int32[B], every n_rows[b] <= n_max <= Ly),
- * d = Ly - n_rows[b].  Columns >= n_rows[b] of out are left untouched. */
-int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
-                      const int32_t* n_rows, int n_max, int B, uint32_t* peak_ws, vfx_stream_t stream);
+/* The same with per-row lengths (ragged batches): row b keeps n_rows[b] samples (device int32[B], every
+ * n_rows[b] <= n_max) of its ly_rows[b] <= Ly vocoder samples (ly_rows NULL: every row has Ly), d = ly_rows[b] - n_rows[b];
+ * the peak is taken over the row's own samples.  Columns >= n_rows[b] of out are left untouched. */
+int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, const int32_t* ly_rows, float* out,
+                      int64_t out_bstride, const int32_t* n_rows, int n_max, int B, uint32_t* peak_ws,
+                      vfx_stream_t stream);
 
 #ifdef __cplusplus
 }

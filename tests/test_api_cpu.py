@@ -159,3 +159,26 @@ def test_wav_length_from_header(tmp_path):
         p = str(tmp_path / ("f%d.wav" % sr))
         wavfile.write(p, sr, (rng.standard_normal((n, 2)) * 1000).astype(np.int16))
         assert audio_io.wav_length(p) == len(audio_io.load_wav(p))
+
+
+def test_plan_batches_ragged_runs():
+    """restore_batch's batch plan: ascending lengths -> runs of <= batch_size utterances whose shortest member has at
+    least ragged_ratio of the frames of the longest; multi-segment files and plugin vocoders fall back to exact
+    lengths; every position appears exactly once and in order."""
+    from voicefixer_amd.api import plan_batches, SEG_LENGTH
+    lens = sorted([441 * 100, 441 * 100 + 5, 441 * 120, 441 * 134, 441 * 200, 441 * 201, SEG_LENGTH, SEG_LENGTH + 1,
+                   SEG_LENGTH + 1, 3 * SEG_LENGTH, 900])
+    plan = plan_batches(lens, batch_size=4, ragged_ratio=0.75)
+    assert [p for _, grp in plan for p in grp] == list(range(len(lens)))
+    kinds = [(k, [lens[p] for p in grp]) for k, grp in plan]
+    assert kinds[0] == ("samples", [900])                                   # too short: alone (raises downstream)
+    assert kinds[1] == ("ragged", [441 * 100, 441 * 100 + 5, 441 * 120])    # 134 frames: 101 < 0.75 * 135
+    assert kinds[2] == ("ragged", [441 * 134])                              # 135 < 0.75 * 201
+    assert kinds[3] == ("ragged", [441 * 200, 441 * 201])                   # the 30 s file is far longer
+    assert kinds[4] == ("ragged", [SEG_LENGTH])
+    assert kinds[5] == ("samples", [SEG_LENGTH + 1, SEG_LENGTH + 1]) and kinds[6] == ("samples", [3 * SEG_LENGTH])
+    for k, grp in plan_batches(lens, 4, 0.75, ragged=False):
+        assert k == "samples" and len({lens[p] for p in grp}) == 1
+    big = plan_batches([441 * 300 + i for i in range(70)], batch_size=32)
+    assert [len(grp) for _, grp in big] == [32, 32, 6]
+    assert plan_batches([], 8) == []

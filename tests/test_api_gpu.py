@@ -426,33 +426,88 @@ def test_hip_graph_replay_is_bit_identical(vf):
     pipe.check()
 
 
-def test_restore_batch_buckets_by_frame_count(vf):
-    """Utterances of different sample counts but one frame count (1 + n // 441) run as ONE batch with per-row lengths
-    in the STFT and the centre trim (vfx_stft_mel_rows_f32 / vfx_post_rows_f32); every row must equal the
-    restoration of that utterance alone bit for bit, and the CPU oracle within the parity tolerance."""
+def test_restore_batch_ragged_rows(vf):
+    """Utterances of DIFFERENT lengths run as ONE launch sequence with per-row lengths in every length-dependent
+    kernel (STFT reflect, GRU reverse start, conv zero/reflect padding, UNet map height, peak rule, centre trim):
+    every row must equal the restoration of that utterance alone (fp32 tile-shape noise only) and the CPU oracle."""
     g = torch.Generator().manual_seed(41)
     T = 37
     lens = [441 * (T - 1), 441 * (T - 1) + 1, 441 * (T - 1) + 220, 441 * T - 1, 441 * (T - 1) + 220]   # all T = 37
     lens += [441 * T, 441 * T + 5]                                                                   # T = 38
+    lens += [441 * 44 + 17, 441 * 47]                                                                # T = 45, 48
     wavs = [(0.1 * torch.randn(n, generator=g)).numpy() for n in lens]
-    pipe = vf._get_pipe()
     before = _lib.lib().vfx_launch_count()
-    outs = vf.restore_batch(wavs, batch_size=8, streams=2)
+    outs = vf.restore_batch(wavs, batch_size=16, streams=2)
     launches = _lib.lib().vfx_launch_count() - before
     single = [vf.restore_inmem(w, cuda=True) for w in wavs]
     per_utt = (_lib.lib().vfx_launch_count() - before - launches) / len(wavs)
-    assert launches < 2.5 * per_utt                      # two buckets, not seven
+    assert launches < 1.5 * per_utt                      # one ragged batch, not nine
     for w, o, s1 in zip(wavs, outs, single):
-        assert o.shape == (1, len(w)) and _rms(o, s1) < 2e-5      # (batch 5 and batch 1 pick different tile shapes)
-    # exactness of the per-row length handling: row r of the mixed batch == row 0 of a batch of the SAME size whose
-    # rows all have length n_r (same launch shapes, so bit for bit)
-    for r in (0, 1, 3):
-        same = torch.from_numpy(np.stack([wavs[r]] * 5)).cuda()
-        want = pipe.restore(same, lens[r])[0].cpu().numpy()
-        assert np.array_equal(outs[r][0], want)
+        assert o.shape == (1, len(w)) and _rms(o, s1) < 2e-5      # (batch 9 and batch 1 pick different tile shapes)
     with torch.no_grad():
         ref = oracle.restore_inmem(wavs[2], *_states(vf))
     assert _rms(outs[2], ref) < 2e-5
-    # the low-level entry refuses rows of different frame counts
     with pytest.raises(_lib.VfxError):
-        pipe.restore_rows(torch.zeros((2, 441 * 40), device="cuda"), [441 * 36, 441 * 39])
+        vf._get_pipe().restore_rows(torch.zeros((2, 441 * 40), device="cuda"), [441 * 36, 1000])   # < 1025 samples
+
+
+def test_ragged_rows_cross_unet_and_tile_boundaries(vf):
+    """Row lengths on both sides of the ResUNet's 64-frame padding (T = 64 | 65 -> maps of 64 | 128 rows), of an odd /
+    even frame count (vocoder tail T%2) and of the 256-column conv tiles; a row of 0.6 x the longest.  Each row vs
+    the utterance alone and vs the oracle; then the two exactness properties that do not depend on tile shapes:
+    (1) equal-length rows pushed through the ragged kernels == the plain batch bit for bit;
+    (2) a row does not change by a single bit when the OTHER rows of the batch change content and length."""
+    pipe = vf._get_pipe()
+    g = torch.Generator().manual_seed(43)
+    lens = [441 * 63 + 3, 441 * 64 + 100, 441 * 100, 441 * 39 + 440, 441 * 104 + 7]   # T = 64, 65, 101, 40, 105
+    n_max = max(lens)
+    wav = torch.zeros((len(lens), n_max))
+    for r, n in enumerate(lens):
+        wav[r, :n] = 0.1 * torch.randn(n, generator=g)
+    wav[3, lens[3]:] = 7.0      # whatever lies past a row's end in the input buffer must not matter
+    wav = wav.cuda()
+    out = pipe.restore_rows(wav, lens)
+    assert out.shape == (len(lens), n_max)
+    worst = 0.0
+    for r, n in enumerate(lens):
+        alone = pipe.restore(wav[r:r + 1, :n].contiguous(), n)[0]
+        e = _rms(out[r, :n].cpu().numpy(), alone.cpu().numpy())
+        worst = max(worst, e)
+        assert e < 2e-5, (r, n, e)
+        assert float(out[r, n:].abs().max()) == 0.0 if n < n_max else True
+    with torch.no_grad():
+        ref = oracle.restore_inmem(wav[3, :lens[3]].cpu().numpy(), *_states(vf))
+    assert _rms(out[3:4, :lens[3]].cpu().numpy(), ref) < 2e-5
+    # (1) the ragged kernels on rows of full length == the plain batched kernels
+    eq = wav[:, :lens[0]].contiguous()
+    assert torch.equal(pipe.restore_rows(eq, [lens[0]] * len(lens), force_ragged=True), pipe.restore(eq, lens[0]))
+    # (2) rows 0 and 4 are unchanged when rows 1..3 become other utterances of other lengths
+    lens2 = [lens[0], 441 * 80 + 9, 441 * 30, 441 * 99 + 1, lens[4]]
+    wav2 = wav.clone()
+    for r in (1, 2, 3):
+        wav2[r] = 0.0
+        wav2[r, :lens2[r]] = 0.1 * torch.randn(lens2[r], generator=g).cuda()
+    out2 = pipe.restore_rows(wav2, lens2)
+    assert torch.equal(out2[0], out[0]) and torch.equal(out2[4], out[4])
+    assert not torch.equal(out2[2], out[2])
+    pipe.check()
+    print("ragged rows vs alone: worst rms error %.3g" % worst)
+
+
+def test_ragged_rows_at_folder_sizes(vf):
+    """Rows of 3-7 s: the launches are large enough for the second-generation kernels (convw, fused ResStack layer),
+    a shorter row ends inside tiles that are INTERIOR for the longest row (the reflect-padded vocoder input conv must
+    mirror there, not zero), and the wide dilations (3^7) reach across row ends."""
+    pipe = vf._get_pipe()
+    g = torch.Generator().manual_seed(47)
+    lens = [441 * 300 + 11, 441 * 520 + 200, 441 * 710 + 5, 441 * 389]
+    wav = torch.zeros((len(lens), max(lens)))
+    for r, n in enumerate(lens):
+        wav[r, :n] = 0.1 * torch.randn(n, generator=g)
+    wav = wav.cuda()
+    out = pipe.restore_rows(wav, lens)
+    for r, n in enumerate(lens):
+        alone = pipe.restore(wav[r:r + 1, :n].contiguous(), n)[0]
+        e = _rms(out[r, :n].cpu().numpy(), alone.cpu().numpy())
+        assert e < 2e-5, (r, n, e)
+    pipe.check()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Folder-style inference on RAGGED lengths (every utterance its own length, i.e. B = 1 buckets): aggregate
-real-time factor of VoiceFixer.restore_batch as a function of the number of HIP streams (device-resident timing
-plus H2D/D2H, host to host)."""
+"""Folder-style inference on RAGGED lengths (every utterance its own length): aggregate real-time factor of
+VoiceFixer.restore_batch (ragged batches with per-row lengths) as a function of the number of HIP streams and of the
+ragged ratio (0.999 = one batch per frame count, the round-1 behaviour), host to host."""
 import argparse
 import os
 import sys
@@ -18,7 +18,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=32)
     ap.add_argument("--math", default="f32")
-    ap.add_argument("--streams", default="1,2,4,8", help="comma-separated stream counts to time")
+    ap.add_argument("--streams", default="1,2,4", help="comma-separated stream counts to time")
+    ap.add_argument("--ratios", default="0.75", help="comma-separated ragged ratios to time")
+    ap.add_argument("--batch", type=int, default=32)
     args = ap.parse_args()
     rng = np.random.default_rng(0)
     lens = rng.integers(5 * 44100, 10 * 44100, size=args.n)
@@ -28,18 +30,20 @@ def main():
     vf.set_math(args.math)
     vf.restore_batch(wavs[:4], streams=2)  # warm-up
     ref = None
-    frames = [1 + int(n) // 441 for n in lens]
-    print("%d utterances, %d distinct frame counts (= buckets of restore_batch)" % (args.n, len(set(frames))))
-    for st in [int(v) for v in args.streams.split(",")]:
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        outs = vf.restore_batch(wavs, streams=st)
-        dt = time.perf_counter() - t0
-        if ref is None:
-            ref = outs
-        err = max(float(np.abs(a - b).max()) for a, b in zip(ref, outs))
-        print("streams=%d: %d ragged utterances (%.0f s of audio) in %.3f s = %.0fx real time (max |diff| vs 1 stream %.1e)"
-              % (st, args.n, total, dt, total / dt, err))
+    from voicefixer_amd.api import plan_batches
+    for ratio in [float(v) for v in args.ratios.split(",")]:
+        plan = plan_batches(sorted(int(n) for n in lens), args.batch, ratio)
+        print("%d utterances, ragged ratio %.3f: %d batches" % (args.n, ratio, len(plan)))
+        for st in [int(v) for v in args.streams.split(",")]:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outs = vf.restore_batch(wavs, streams=st, batch_size=args.batch, ragged_ratio=ratio)
+            dt = time.perf_counter() - t0
+            if ref is None:
+                ref = outs
+            err = max(float(np.abs(a - b).max()) for a, b in zip(ref, outs))
+            print("  streams=%d: %d ragged utterances (%.0f s of audio) in %.3f s = %.0fx real time (max |diff| vs first run %.1e)"
+                  % (st, args.n, total, dt, total / dt, err))
 
 
 if __name__ == "__main__":

@@ -19,7 +19,7 @@ class VfxError(RuntimeError):
 
 class vfx_tensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("bstride", C.c_int64), ("cstride", C.c_int64),
-                ("lstride", C.c_int64), ("guard", C.c_int64)]
+                ("lstride", C.c_int64), ("guard", C.c_int64), ("rows", C.c_void_p)]
 
 
 class vfx_act(C.Structure):
@@ -54,7 +54,8 @@ SIGNATURES = {
     "vfx_frontend_readback": (_I, [_I, _P, _P, _P, _P, _I, C.POINTER(_I)]),
     "vfx_stft_mel_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
     "vfx_stft_mel_rows_f32": (_I, [_P, C.c_int64, _I, _P, _I, _P, _P]),
-    "vfx_post_rows_f32": (_I, [_P, C.c_int64, _I, _P, C.c_int64, _P, _I, _I, _P, _P]),
+    "vfx_post_rows_f32": (_I, [_P, C.c_int64, _I, _P, _P, C.c_int64, _P, _I, _I, _P, _P]),
+    "vfx_mel_to_cond_rows_f32": (_I, [_P, _T, _I, _I, _P, _I, _P]),
     "vfx_frontend_init_oracle": (_I, [_P, _P, _P, _P, _I]),
     "vfx_peak_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P]),
     "vfx_stft_mel_oracle_f32": (_I, [_P, C.c_int64, _I, _I, _P, _P, _P]),

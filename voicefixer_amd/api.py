@@ -55,6 +55,30 @@ def _load_restorer_state(path):
     return out, (voc or None)  # vf.ckpt may overwrite the vocoder weights
 
 
+def plan_batches(sorted_lengths, batch_size, ragged_ratio=0.75, ragged=True):
+    """Cut a list of ASCENDING sample counts into batches: ("ragged", [positions]) for runs of utterances of
+    1025..SEG_LENGTH samples whose shortest member has >= ragged_ratio of the frames (1 + n // 441) of the longest
+    (Pipeline.restore_rows), ("samples", [positions]) for runs of exactly equal length otherwise (files of several
+    segments, plugin vocoders, too-short files -- the last raise in the pipeline as the reference does)."""
+    plan = []
+    i, n_items = 0, len(sorted_lengths)
+    while i < n_items:
+        n0 = sorted_lengths[i]
+        j = i + 1
+        if ragged and 1025 <= n0 <= SEG_LENGTH:
+            t0 = 1 + n0 // 441
+            while (j < n_items and j - i < batch_size and sorted_lengths[j] <= SEG_LENGTH and
+                   t0 >= ragged_ratio * (1 + sorted_lengths[j] // 441)):
+                j += 1
+            plan.append(("ragged", list(range(i, j))))
+        else:
+            while j < n_items and j - i < batch_size and sorted_lengths[j] == n0:
+                j += 1
+            plan.append(("samples", list(range(i, j))))
+        i = j
+    return plan
+
+
 def plan_stream_chunks(n, chunk, overlap):
     """Chunk starts / lengths of the overlap-add streaming mode: chunks of ``chunk`` samples every
     ``chunk - overlap`` samples; the last one is shorter.  A tail that would be too short to restore
@@ -257,52 +281,45 @@ class VoiceFixer(nn.Module):
         return pipe.restore(seg, n, your_vocoder_func)
 
     @torch.no_grad()
-    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=4):
+    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=2, ragged_ratio=0.75):
         """Batched folder inference (not in the reference, which loops files at B=1,
         voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i).
-        Utterances of up to 30 s are bucketed by FRAME COUNT T = 1 + n // 441: only the STFT's reflect padding and the
-        final centre trim see the sample count n (per-row lengths in those two kernels), everything between depends
-        on T alone, so a bucket is one batched launch sequence whose rows are identical to restoring each utterance
-        alone (a folder of 2048 files of 5-10 s has ~4 files per frame count; a small ragged folder still has mostly
-        single-file buckets).  Longer files (several 30 s segments) are bucketed by exact length, one batched launch
-        sequence per segment index.  Buckets go round-robin to ``streams`` HIP streams: the low-occupancy phases of one
-        bucket (GRU recurrence, deep UNet levels) overlap the convolutions of the next, and single-file buckets run
-        several at a time on a chip that one utterance cannot fill."""
+        Utterances of up to 30 s go through RAGGED batches: the length-sorted list is cut into runs of up to
+        ``batch_size`` files whose shortest member has at least ``ragged_ratio`` of the frames of the longest, and a run
+        is ONE launch sequence in which every kernel takes the per-row lengths (Pipeline.restore_rows) -- each row is
+        what restoring that utterance alone returns, the tiles past a row's end are skipped, only the buffers are
+        sized for the longest row.  Longer files (several 30 s segments) and plugin vocoders are bucketed by exact
+        length, one batched launch sequence per segment index.  Batches go round-robin to ``streams`` HIP streams: the
+        low-occupancy phases of one batch (GRU recurrence, deep UNet levels) overlap the convolutions of the next."""
         pipe = self._get_pipe()
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
-        pool = [torch.cuda.Stream(device=pipe.device) for _ in range(max(1, int(streams)))]
+        # the SAME stream objects on every call: torch's caching allocator keeps one block pool per stream, so fresh
+        # streams per call (torch hands them out round-robin from 32) would strand a batch's worth of HBM in a new
+        # pool each time until the allocator has to flush everything (measured: a 5x slower call after ~6 calls)
+        if not hasattr(self, "_stream_pool"):
+            self._stream_pool = []
+        while len(self._stream_pool) < max(1, int(streams)):
+            self._stream_pool.append(torch.cuda.Stream(device=pipe.device))
+        pool = self._stream_pool[:max(1, int(streams))]
         pipe.set_streams(len(pool))
         main = torch.cuda.current_stream(pipe.device)
         for st in pool:
             st.wait_stream(main)
-
-        def key(k):  # bucket key of utterance k
-            n = len(wavs[k])
-            if your_vocoder_func is None and 1025 <= n <= SEG_LENGTH:
-                return ("frames", 1 + n // 441)
-            return ("samples", n)
-
         pending = []
-        i = 0
-        nb = 0
-        while i < len(order):
-            kind, val = key(order[i])
-            grp = [k for k in order[i:i + batch_size] if key(k) == (kind, val)]
+        for nb, (kind, grp) in enumerate(plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio,
+                                                     ragged=your_vocoder_func is None)):
+            grp = [order[g] for g in grp]
             with torch.cuda.stream(pool[nb % len(pool)]):
-                if kind == "frames":
+                if kind == "ragged":
                     lens = [len(wavs[k]) for k in grp]
-                    if min(lens) == max(lens):
-                        seg = np.stack([np.asarray(wavs[k], np.float32) for k in grp])
-                        full = pipe.restore(torch.from_numpy(seg).to(pipe.device), lens[0], None)
-                    else:
-                        seg = np.zeros((len(grp), max(lens)), np.float32)
-                        for r, k in enumerate(grp):
-                            seg[r, :lens[r]] = np.asarray(wavs[k], np.float32)
-                        full = pipe.restore_rows(torch.from_numpy(seg).to(pipe.device), lens)
+                    seg = np.zeros((len(grp), max(lens)), np.float32)
+                    for r, k in enumerate(grp):
+                        seg[r, :lens[r]] = np.asarray(wavs[k], np.float32)
+                    full = pipe.restore_rows(torch.from_numpy(seg).to(pipe.device), lens)
                     pending.append((grp, lens, full))
                 else:
-                    n = val
+                    n = len(wavs[grp[0]])
                     parts = []
                     for s0 in range(0, n, SEG_LENGTH):
                         seg = np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH] for k in grp])
@@ -310,8 +327,6 @@ class VoiceFixer(nn.Module):
                                                   seg.shape[1], your_vocoder_func))
                     full = torch.cat(parts, -1)
                     pending.append((grp, [full.shape[-1]] * len(grp), full))
-            i += len(grp)
-            nb += 1
         torch.cuda.synchronize(pipe.device)
         pipe.set_streams(1)
         pipe.check()

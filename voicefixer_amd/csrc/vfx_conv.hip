@@ -109,6 +109,8 @@ struct ConvArgs {
     const float* wd;        // weights packed [slab][Cin/8][Cout][8 channels in the order 0,2,4,6,1,3,5,7]
     int kcx;                // channels per activation chunk (8, 16 or 32)
     int ntiles_l, xcd_chunk;      // tiles along L; XCD-aware tile order: tiles per XCD (0 = linear order)
+    const int* x_rows;            // ragged batches: valid input length of batch item b (device int32[B]) or NULL (= Lin)
+    int lq_extra;                 // ... its valid output-position count is x_rows[b] + lq_extra (1 for transposed 1-D convs)
     int stagger, stagger_wgs;     // development: start stagger of the first residency round (s_sleep units, workgroups)
     int w_tap0, w_tapstep, w_slab0, w_slabstep, w_slab_ph, w_ooff0, w_ooff_ph, w_nseg, w_seg0, w_segstep;  // tap geometry (affine)
     // fused ResStack layer: second convolution (k3, dilation 1) and the LDS tile between the two
@@ -143,7 +145,7 @@ struct StageState {
 template <bool FAST, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const ConvArgs& a,
                                            const float* __restrict__ xb, int xcs, int c0, int lshift,
-                                           __amdgpu_buffer_rsrc_t xrsrc, __amdgpu_buffer_rsrc_t wrsrc) {
+                                           __amdgpu_buffer_rsrc_t xrsrc, __amdgpu_buffer_rsrc_t wrsrc, int Lin_row) {
     if constexpr (FAST) {
         // buffer loads: per-slot byte offset in one VGPR (fixed for the whole K loop) + the chunk's offset
         // in an SGPR -> no 64-bit address arithmetic per load
@@ -167,7 +169,7 @@ __device__ __forceinline__ void stage_load(StageState<MAXXV, MAXWV>& st, const C
         if constexpr (FAST) {
             st.xv[j] = *reinterpret_cast<const float4*>(xc + st.x_off[j]);
         } else {
-            const int Lin = a.Lin;
+            const int Lin = Lin_row;
             const bool reflect = a.pad_mode == VFX_PAD_REFLECT;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int kc = st.x_kc[j];
@@ -228,7 +230,7 @@ __device__ __forceinline__ void stage_write_plain(StageState<MAXXV, MAXWV>& st, 
 template <bool FAST, int NTHR, int MAXXV, int MAXWV>
 __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const ConvArgs& a, int c0, float* xs,
                                             float* ws, const float* aff, int nxv, int nwv, int xtotal,
-                                            int wtotal, int tid, int lshift, bool range_mask) {
+                                            int wtotal, int tid, int lshift, bool range_mask, int Lin_row) {
     const int pre_act = a.pre_act;
     const float pre_slope = a.pre_slope;
     const int in_mask = a.in_mask;
@@ -251,7 +253,7 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                     if (a.pad_mode != VFX_PAD_REFLECT) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            if (l + k < 0 || l + k >= a.Lin || cbad) e[k] = 0.f;
+                            if (l + k < 0 || l + k >= Lin_row || cbad) e[k] = 0.f;
                     }
                 }
             }
@@ -261,7 +263,7 @@ __device__ __forceinline__ void stage_write(StageState<MAXXV, MAXWV>& st, const 
                     const int l = st.x_l[j] + lshift;
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (l + k < 0 || l + k >= a.Lin) e[k] = 0.f;
+                        if (l + k < 0 || l + k >= Lin_row) e[k] = 0.f;
                 }
             }
             if (in_mask >= 3) {
@@ -472,13 +474,18 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     if constexpr (FAST) tile += a.tile_lo;
     else if (tile >= a.tile_lo) tile += a.tile_hi - a.tile_lo;
     const int q0 = tile * a.bl_step;
-    const int qend = min(a.Lq, q0 + a.bl_step);
     const int m0g = blockIdx.y * BM;
     const int ph = m0g / a.Cout;
     const int m0 = m0g - ph * a.Cout;
     const int ksplit = SPLITK ? a.ksplit : 1;
     const int b = SPLITK ? blockIdx.z / ksplit : blockIdx.z;
     const int ks = SPLITK ? blockIdx.z - b * ksplit : 0;
+    // ragged batches: every batch item has its own valid length; positions past it are zero padding of the
+    // (activated) input, tiles past its last output position have nothing to do
+    const int Lin_row = a.x_rows ? __builtin_amdgcn_readfirstlane(a.x_rows[b]) : a.Lin;
+    const int Lq_row = a.x_rows ? Lin_row + a.lq_extra : a.Lq;
+    if (q0 >= Lq_row && !SPLITK) return;
+    const int qend = min(Lq_row, q0 + a.bl_step);
     const PhaseTab* __restrict__ pt = &a.tab->ph[ph];
     // block-uniform table entries: readfirstlane makes the uniformity provable (SGPRs, scalar branches)
     const int nt = __builtin_amdgcn_readfirstlane(pt->ntaps);
@@ -558,19 +565,19 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
     const int S = SPLITK ? min(a.cpp, nchunks - cbase) : nchunks;
     int ch1 = cbase + 1, ch2 = cbase + 2;  // chunk held in registers / chunk being loaded at the top of step s
     constexpr int ti1 = 0, ti2 = 0;
-    stage_load<FAST>(st, a, xb, xcs, cbase * KC, 0, xrsrc, wrsrc);
+    stage_load<FAST>(st, a, xb, xcs, cbase * KC, 0, xrsrc, wrsrc, Lin_row);
     // does any staged vector of this tile leave [0, Lin)?  (uniform; only possible with a guard band)
     bool range_mask = false;
     if constexpr (FAST) {
         for (int sg = 0; sg < nseg; ++sg) {
             const int o = q0 + __builtin_amdgcn_readfirstlane(pt->seg_org[sg]);
-            range_mask |= (o < 0) || (o + segw > a.Lin);
+            range_mask |= (o < 0) || (o + segw > Lin_row);
         }
     }
     const bool plain = FAST && !range_mask && a.in_mask == 0 && a.pre_act != VFX_PRE_AFFINE_LRELU;
     if (plain) stage_write_plain<NTHR>(st, a, smem, smem + a.xs_floats, nxv, nwv, xtotal, wtotal, tid);
-    else stage_write<FAST, NTHR>(st, a, cbase * KC, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask);
-    if (S > 1) stage_load<FAST>(st, a, xb, xcs, (cbase + 1) * KC, 0, xrsrc, wrsrc);
+    else stage_write<FAST, NTHR>(st, a, cbase * KC, smem, smem + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid, 0, range_mask, Lin_row);
+    if (S > 1) stage_load<FAST>(st, a, xb, xcs, (cbase + 1) * KC, 0, xrsrc, wrsrc, Lin_row);
     __syncthreads();
 #if VFX_ABL & 8
     unsigned long long d_write = 0, d_load = 0, d_mfma = 0, d_bar = 0;
@@ -585,14 +592,14 @@ __global__ __launch_bounds__(64 * WGM * WGL, WGM * WGL / 2) void conv_taps_kerne
             float* nxs = smem + ((s + 1) & 1) * bufstride;
             if (plain) stage_write_plain<NTHR>(st, a, nxs, nxs + a.xs_floats, nxv, nwv, xtotal, wtotal, tid);
             else stage_write<FAST, NTHR>(st, a, ch1 * KC, nxs, nxs + a.xs_floats, aff, nxv, nwv, xtotal, wtotal, tid,
-                                         ti1 * BL, range_mask);
+                                         ti1 * BL, range_mask, Lin_row);
 #if VFX_ABL & 8
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         }
         DBG_T(t1);
         if (s + 1 < S) {
-            if (s + 2 < S) stage_load<FAST>(st, a, xb, xcs, ch2 * KC, ti2 * BL, xrsrc, wrsrc);
+            if (s + 2 < S) stage_load<FAST>(st, a, xb, xcs, ch2 * KC, ti2 * BL, xrsrc, wrsrc, Lin_row);
         }
 #endif
         DBG_T(t2);
@@ -1213,7 +1220,7 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
                          hipStream_t stream) {
     const int Cin = a.Cin, Cout = a.Cout, B = a.B, Lq = a.Lq, Lin = a.Lin;
     if (!w3 || !vfx_aligned16(w3) || Cin % 32 != 0 || Cout % 32 != 0) return VFX_ENOTSUP;
-    if (a.pad_mode == VFX_PAD_REFLECT) return VFX_ENOTSUP;
+    if (a.pad_mode == VFX_PAD_REFLECT || a.x_rows) return VFX_ENOTSUP;  // (no per-row lengths in the bf16x3 kernel)
     // (raw buffer resource, 32-bit byte offsets within one batch item: see launch_conv)
     if (((long long)a.CinPad * x->cstride + Lin + 2 * x->guard) * 4 >= (1ll << 31) - (1ll << 20)) return VFX_ENOTSUP;
     // 3x3 on a pitch map (9 taps (ky-1)*P + (kx-1), slab ky*3+kx) -> 3 kernel rows x the 3-tap dx case
@@ -1353,6 +1360,8 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     a.Lin = Lin; a.Lq = Lq; a.Lout = Lout;
     a.x_bs = x->bstride; a.x_cs = x->cstride;
     a.x_guard = (x->guard > 0 && pad_mode != VFX_PAD_REFLECT) ? (int)x->guard : 0;
+    a.x_rows = x->rows;
+    a.lq_extra = Lq - Lin;
     a.y_bs = y->bstride; a.y_cs = y->cstride; a.y_ls = y->lstride;
     if (res) { a.r_bs = res->bstride; a.r_cs = res->cstride; a.r_ls = res->lstride; }
     a.q_shift = q_shift; a.q_mask = q_mask; a.o_rs = o_rs; a.o_cs = o_cs;
@@ -1482,6 +1491,9 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         // (num_records 2^31 - 1: anything beyond reads as zero): rows of a batch item spanning 2 GB or more (a
         // 64-channel stage of > 3 minutes) run the general, pointer-addressed instance on every tile
         if (((long long)a.CinPad * x->cstride + Lin + 2 * g) * 4 >= (1ll << 31) - (1ll << 20)) { tlo = 0; thi = 0; }
+        // ragged batches: a tile that is interior for the longest row holds the END of a shorter one, and only the
+        // general instance mirrors there (the interior one can only zero what lies outside the row)
+        if (a.x_rows && pad_mode == VFX_PAD_REFLECT) { tlo = 0; thi = 0; }
         a.tile_lo = tlo;
         a.tile_hi = thi;
         if (exact && !(tlo == 0 && thi == ntiles)) { exact = false; continue; }  // boundary tiles: aligned layout

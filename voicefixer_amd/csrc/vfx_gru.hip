@@ -34,7 +34,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(512, 1) void gru_kernel(const float* __restrict__ gi, const float* __restrict__ wpk,
                                                      const float* __restrict__ bhh, float* __restrict__ out,
-                                                     long long o_bs, long long o_cs, int T) {
+                                                     long long o_bs, long long o_cs, int Tpitch,
+                                                     const int* __restrict__ t_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* wl = lds;                               // [2][KLDS][768]
     float* hbuf = wl + GRU_L_FLOATS;               // [2][256]
@@ -42,10 +43,13 @@ __global__ __launch_bounds__(512, 1) void gru_kernel(const float* __restrict__ g
     const int tid = threadIdx.x;
     const int j = tid & 255, half = tid >> 8;
     const int b = blockIdx.x, dir = blockIdx.y;
+    // ragged batches: this sequence has t_rows[b] frames (the reverse direction starts at its own last frame);
+    // Tpitch is the frame pitch of gi
+    const int T = t_rows ? t_rows[b] : Tpitch;
     const float* Wd = wpk + (long long)dir * (GRU_R_FLOATS + GRU_L_FLOATS + GRU_S_FLOATS);
     const float* WR = Wd + (long long)half * GRU_KREG * GRU_G;
     const float* WL = Wd + GRU_R_FLOATS;
-    const float* g = gi + (long long)b * T * (2 * GRU_G) + dir * GRU_G;
+    const float* g = gi + (long long)b * Tpitch * (2 * GRU_G) + dir * GRU_G;
     float* o = out + (long long)b * o_bs + (long long)(dir * GRU_H + j) * o_cs;
 
     float wr[GRU_KREG], wz[GRU_KREG], wn[GRU_KREG];
@@ -191,7 +195,7 @@ extern "C" int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const
         attr_set = true;
     }
     hipLaunchKernelGGL(gru_kernel, dim3(B, 2), dim3(512), lds, (hipStream_t)stream, gi, whh_packed, bhh,
-                       (float*)out->ptr, out->bstride, out->cstride, T);
+                       (float*)out->ptr, out->bstride, out->cstride, T, (const int*)out->rows);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -221,8 +225,8 @@ typedef unsigned long long u64;
 
 __global__ __launch_bounds__(512, 2) void gru2_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
                                                       const float* __restrict__ bhh, float* __restrict__ out,
-                                                      long long o_bs, long long o_cs, int T, u64* __restrict__ mbox,
-                                                      int* __restrict__ err) {
+                                                      long long o_bs, long long o_cs, int Tpitch, u64* __restrict__ mbox,
+                                                      int* __restrict__ err, const int* __restrict__ t_rows) {
     __shared__ float hloc[2][128];
     __shared__ float part[3][256];
     const int tid = threadIdx.x;
@@ -230,8 +234,9 @@ __global__ __launch_bounds__(512, 2) void gru2_kernel(const float* __restrict__ 
     const int wg = blockIdx.x;
     const int r = wg & 1, pair = wg >> 1;
     const int dir = pair & 1, b = pair >> 1;
+    const int T = t_rows ? t_rows[b] : Tpitch;   // ragged batches: frames of this sequence (both partners read the same value)
     const float* W = whh_t + (long long)dir * GRU_H * GRU_G + (long long)(r * 128 + kq * 64) * GRU_G;
-    const float* g = gi + (long long)b * T * (2 * GRU_G) + dir * GRU_G;
+    const float* g = gi + (long long)b * Tpitch * (2 * GRU_G) + dir * GRU_G;
     const bool mine = (j >> 7) == r;       // unit j is finalised by this workgroup
     const int ju = j & 127;
     float* o = out + (long long)b * o_bs + (long long)(dir * GRU_H + j) * o_cs;
@@ -349,7 +354,7 @@ extern "C" int vfx_gru_bidir2_f32(const float* gi, const float* whh_t, const flo
     hipError_t e = hipMemsetAsync(mailbox, 0, need, s);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(gru2_kernel, dim3(B * 4), dim3(512), 0, s, gi, whh_t, bhh, (float*)out->ptr, out->bstride,
-                       out->cstride, T, (u64*)mailbox, (int*)err_flag);
+                       out->cstride, T, (u64*)mailbox, (int*)err_flag, (const int*)out->rows);
     VFX_LAUNCHED();
     return vfx_last_error();
 }

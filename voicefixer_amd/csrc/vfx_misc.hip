@@ -16,10 +16,11 @@ template <int K>
 __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict__ x, long long x_bs,
                                                          long long x_cs, const float* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ y,
-                                                         long long y_bs, int Cin, int L, int reflect, int post_act,
-                                                         int out_mask) {
+                                                         long long y_bs, int Cin, int L0, int reflect, int post_act,
+                                                         int out_mask, const int* __restrict__ rows) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     const int b = blockIdx.y;
+    const int L = rows ? rows[b] : L0;   // ragged batches: zero / reflect padding at this row's own end
     if (l >= L) return;
     int idx[K];
     bool ok[K];
@@ -62,10 +63,11 @@ extern "C" int vfx_conv1d_cout1_f32(const vfx_tensor* x, const float* w, const f
     hipStream_t s = (hipStream_t)stream;
     if (k == 7)
         hipLaunchKernelGGL(conv_cout1_kernel<7>, grid, dim3(256), 0, s, (const float*)x->ptr, x->bstride, x->cstride,
-                           w, bias, (float*)y->ptr, y->bstride, Cin, L, pad_mode == VFX_PAD_REFLECT, post_act, mask);
+                           w, bias, (float*)y->ptr, y->bstride, Cin, L, pad_mode == VFX_PAD_REFLECT, post_act, mask,
+                           (const int*)x->rows);
     else if (k == 1)
         hipLaunchKernelGGL(conv_cout1_kernel<1>, grid, dim3(256), 0, s, (const float*)x->ptr, x->bstride, x->cstride,
-                           w, bias, (float*)y->ptr, y->bstride, Cin, L, 0, post_act, mask);
+                           w, bias, (float*)y->ptr, y->bstride, Cin, L, 0, post_act, mask, (const int*)x->rows);
     else
         return VFX_EINVAL;
     VFX_LAUNCHED();
@@ -139,11 +141,13 @@ extern "C" int vfx_tm_to_cm_f32(const float* src, float* dst, int B, int T, int 
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict__ mel, const float* __restrict__ mask,
                                                          long long m_bs, long long m_cs, float* __restrict__ u,
-                                                         long long u_bs, long long u_cs, int nch, int T, int Tp) {
+                                                         long long u_bs, long long u_cs, int nch, int T0, int Tp,
+                                                         const int* __restrict__ t_rows) {
     // block = 32 frames x 128 bins; mask is channel-major so it goes through an LDS transpose
     __shared__ float tile[128][33];
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
     const int tid = threadIdx.x;
+    const int T = t_rows ? t_rows[b] : T0;   // ragged batches: frames of this row (mel rows are T0 apart); zeros from T on
     {
         const int tx = tid & 31, cy = tid >> 5;  // 32 t x 8 c
         for (int c = cy; c < 128; c += 8) {
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(256) void unet_input_kernel(const float* __restrict
         if (t >= Tp) break;
         float a0 = 0.f, a1 = 0.f;
         if (t < T && c < 127) {
-            const float m = mel[((long long)b * T + t) * 128 + c];
+            const float m = mel[((long long)b * T0 + t) * 128 + c];
             a0 = log10f(fmaxf(m, 1e-8f));
             a1 = log10f(fmaxf(tile[c][r] * m, 1e-8f));
         }
@@ -178,7 +182,7 @@ extern "C" int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, cons
     dim3 grid((Tp + 31) / 32, B);
     hipLaunchKernelGGL(unet_input_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel, (const float*)mask->ptr,
                        mask->bstride, mask->cstride, (float*)unet_in->ptr, unet_in->bstride, unet_in->cstride, nch, T,
-                       Tp);
+                       Tp, (const int*)mask->rows);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -228,11 +232,13 @@ extern "C" int vfx_unet_output_f32(const vfx_tensor* unet_out, const vfx_tensor*
 // vocoder front-end: mel (B,T,128) -> cond (B,128,T') channel-major
 // --------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mel_to_cond_kernel(const float* __restrict__ mel, float* __restrict__ cond,
-                                                          long long c_bs, long long c_cs, int T, int Tc,
-                                                          int apply_weight) {
+                                                          long long c_bs, long long c_cs, int T0, int Tc0,
+                                                          int apply_weight, const int* __restrict__ t_rows) {
     __shared__ float tile[32][129];
     const int b = blockIdx.y, t0 = blockIdx.x * 32;
     const int tid = threadIdx.x;
+    const int T = t_rows ? t_rows[b] : T0;               // ragged batches: this row's frames (mel rows are T0 apart)
+    const int Tc = t_rows ? T + (T & 1) + 4 : Tc0;       // ... and its own tail padding
     {
         const int c = tid & 127;
         // w_k = a*exp(b*k), k = 1..128 in float32 (config.py:296-316: torch.linspace then exp)
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256) void mel_to_cond_kernel(const float* __restric
             const int t = t0 + r;
             float v = -4.0f;
             if (t < T) {
-                const float m = fabsf(mel[((long long)b * T + t) * 128 + c] / wgt);
+                const float m = fabsf(mel[((long long)b * T0 + t) * 128 + c] / wgt);
                 const float S = 20.f * log10f(fmaxf(1e-5f, m)) - 20.f;
                 v = fminf(fmaxf(8.f * ((S + 115.f) / 115.f) - 4.f, -4.f), 4.f);
             }
@@ -257,6 +263,8 @@ __global__ __launch_bounds__(256) void mel_to_cond_kernel(const float* __restric
     }
 }
 
+extern "C" int vfx_mel_to_cond_rows_f32(const float* mel, const vfx_tensor* cond, int B, int T, const int32_t* t_rows,
+                                        int apply_weight, vfx_stream_t stream);
 extern "C" int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int T, int apply_weight,
                                       vfx_stream_t stream);
 extern "C" int vfx_mel_to_cond_f32(const float* mel, const vfx_tensor* cond, int B, int T, vfx_stream_t stream) {
@@ -265,12 +273,19 @@ extern "C" int vfx_mel_to_cond_f32(const float* mel, const vfx_tensor* cond, int
 
 extern "C" int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, int B, int T, int apply_weight,
                                       vfx_stream_t stream) {
+    return vfx_mel_to_cond_rows_f32(mel, cond, B, T, nullptr, apply_weight, stream);
+}
+
+// t_rows (device int32[B], may be NULL): frames of every row; T is then the row pitch of mel (>= every t_rows[b]) and
+// row b is written up to its own t_rows[b] + t_rows[b]%2 + 4 frames
+extern "C" int vfx_mel_to_cond_rows_f32(const float* mel, const vfx_tensor* cond, int B, int T, const int32_t* t_rows,
+                                        int apply_weight, vfx_stream_t stream) {
     if (!mel || !cond || !cond->ptr || B <= 0 || T <= 0 || B > 65535) return VFX_EINVAL;
     if (cond->lstride != 1) return VFX_EALIGN;
-    const int Tc = T + (T & 1) + 4;
+    const int Tc = T + (T & 1) + 4;   // (>= every row's own t + t%2 + 4: the even ceiling is monotone)
     dim3 grid((Tc + 31) / 32, B);
     hipLaunchKernelGGL(mel_to_cond_kernel, grid, dim3(256), 0, (hipStream_t)stream, mel, (float*)cond->ptr,
-                       cond->bstride, cond->cstride, T, Tc, apply_weight);
+                       cond->bstride, cond->cstride, T, Tc, apply_weight, (const int*)t_rows);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -278,9 +293,10 @@ extern "C" int vfx_mel_to_cond_ex_f32(const float* mel, const vfx_tensor* cond, 
 // --------------------------------------------------------------------------------------
 // peak rule + centre trim
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ y, long long y_bs, int Ly,
-                                                   uint32_t* __restrict__ peak) {
+__global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ y, long long y_bs, int Ly0,
+                                                   uint32_t* __restrict__ peak, const int* __restrict__ ly_rows) {
     const int b = blockIdx.y;
+    const int Ly = ly_rows ? ly_rows[b] : Ly0;   // ragged batches: the peak is taken over this row's own samples
     const float* p = y + (long long)b * y_bs;
     float m = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < Ly; i += (long long)gridDim.x * 256)
@@ -298,10 +314,11 @@ __global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ y, 
 __global__ __launch_bounds__(256) void trim_kernel(const float* __restrict__ y, long long y_bs, int start0,
                                                    float* __restrict__ out, long long o_bs, int N0,
                                                    const uint32_t* __restrict__ peak, const int* __restrict__ n_rows,
-                                                   int Ly) {
+                                                   int Ly0, const int* __restrict__ ly_rows) {
     const int b = blockIdx.y;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int N = n_rows ? n_rows[b] : N0;                 // per-utterance length (vfx_post_rows_f32)
+    const int Ly = ly_rows ? ly_rows[b] : Ly0;
     const int start = n_rows ? (Ly - N) / 2 : start0;      // _trim_center: drop (Ly - N) // 2 samples in front
     if (i >= N) return;
     const float pk = __uint_as_float(peak[b]);
@@ -317,7 +334,7 @@ extern "C" int vfx_peak_f32(const float* y, int64_t y_bstride, int Ly, int B, ui
     if (e != hipSuccess) return (int)e;
     int nb = (Ly + 255) / 256;
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak);
+    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak, (const int*)nullptr);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
@@ -330,28 +347,31 @@ extern "C" int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* ou
     if (e != hipSuccess) return (int)e;
     int nb = (Ly + 255) / 256;
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws);
+    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws, (const int*)nullptr);
     VFX_LAUNCHED();
     const int d = Ly - N;
     hipLaunchKernelGGL(trim_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, y, (long long)y_bstride, d / 2, out,
-                       (long long)out_bstride, N, peak_ws, (const int*)nullptr, Ly);
+                       (long long)out_bstride, N, peak_ws, (const int*)nullptr, Ly, (const int*)nullptr);
     VFX_LAUNCHED();
     return vfx_last_error();
 }
 
-// Per-row lengths: row b keeps n_rows[b] <= n_max <= Ly samples (device int32[B]); out rows are n_max apart at least.
-extern "C" int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, float* out, int64_t out_bstride,
-                                 const int32_t* n_rows, int n_max, int B, uint32_t* peak_ws, vfx_stream_t stream) {
+// Per-row lengths: row b keeps n_rows[b] <= n_max samples (device int32[B]) of its ly_rows[b] <= Ly vocoder samples
+// (ly_rows NULL: every row has Ly); the peak rule looks at the row's own samples only.
+extern "C" int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, const int32_t* ly_rows, float* out,
+                                 int64_t out_bstride, const int32_t* n_rows, int n_max, int B, uint32_t* peak_ws,
+                                 vfx_stream_t stream) {
     if (!y || !out || !peak_ws || !n_rows || B <= 0 || n_max <= 0 || Ly < n_max || B > 65535) return VFX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(peak_ws, 0, sizeof(uint32_t) * B, s);
     if (e != hipSuccess) return (int)e;
     int nb = (Ly + 255) / 256;
     if (nb > 256) nb = 256;
-    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws);
+    hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws,
+                       (const int*)ly_rows);
     VFX_LAUNCHED();
     hipLaunchKernelGGL(trim_kernel, dim3((n_max + 255) / 256, B), dim3(256), 0, s, y, (long long)y_bstride, 0, out,
-                       (long long)out_bstride, n_max, peak_ws, (const int*)n_rows, Ly);
+                       (long long)out_bstride, n_max, peak_ws, (const int*)n_rows, Ly, (const int*)ly_rows);
     VFX_LAUNCHED();
     return vfx_last_error();
 }

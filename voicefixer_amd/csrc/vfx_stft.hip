@@ -102,13 +102,14 @@ __global__ __launch_bounds__(256) void stft_mel_kernel(const float* __restrict__
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const float* x = wav + (long long)b * wav_stride;
-    const int N = n_rows ? n_rows[b] : N0;   // per-utterance sample count (rows of one frame count T batched together)
+    const int N = n_rows ? n_rows[b] : N0;   // per-utterance sample count (ragged batches); T is then the row PITCH of mel
+    const int Trow = n_rows ? 1 + N / HOP : T;
 
     for (int i = tid; i < NFFT / 2; i += 256) tw[i] = twiddle[i];
 
     for (int f = 0; f < FPW; ++f) {
         const int t = blockIdx.x * FPW + f;
-        if (t >= T) break;  // uniform
+        if (t >= Trow) break;  // uniform
         // ---- windowed frame.  restore path: reflect index map x_p[n] = x[reflect(HOP*t + n - 1024)];
         // Vocoder.oracle path (librosa >= 0.10 stft): zero padding and the wav / max|wav| pre-scale
         const int base = HOP * t - NFFT / 2;
@@ -180,8 +181,8 @@ extern "C" int vfx_stft_mel_f32(const float* wav, int64_t wav_stride, int B, int
     return vfx_last_error();
 }
 
-// The same for a batch whose rows have DIFFERENT sample counts but the same frame count T = 1 + n/441 (n_rows: device
-// int32[B], every n_rows[b] in [441*(T-1), 441*T) and >= 1025): everything downstream of the mel depends on T only.
+// The same for a batch whose rows have DIFFERENT sample counts (n_rows: device int32[B], every n_rows[b] >= 1025):
+// row b gets its own 1 + n_rows[b]/441 frames, T is the row pitch of mel (>= every row's frame count).
 extern "C" int vfx_stft_mel_rows_f32(const float* wav, int64_t wav_stride, int B, const int32_t* n_rows, int T, float* mel,
                                      vfx_stream_t stream) {
     if (!wav || !mel || !n_rows || B <= 0 || T < 3 || B > 65535) return VFX_EINVAL;

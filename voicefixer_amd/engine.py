@@ -36,8 +36,35 @@ G_TILE = 256 + 8
 G_DIL = 3 ** 7 + G_TILE  # largest ResStack dilation
 
 
-def _rows(B, Cn, L, guard, dev):
-    return ops.guarded(B, Cn, L, guard, dev)
+def _rows(B, Cn, L, guard, dev, rows=None):
+    """Guarded (B, C, L) activation buffer; ``rows`` (device int32 (B,)) tags it with the valid length of every batch
+    item (ragged batches): a kernel that READS the buffer pads at each row's own end and skips the tiles past it."""
+    v = ops.guarded(B, Cn, L, guard, dev)
+    if rows is not None:
+        ops.with_rows(v, rows)
+    return v
+
+
+class RaggedRows:
+    """Per-utterance lengths of a ragged batch at every stage of the path, as device int32 vectors (one H2D copy).
+    Utterance b has n_b samples -> T_b = 1 + n_b // 441 frames; the ResUNet sees Tp_b = T_b rounded up to 64 rows
+    (restorer/model_kqq_bn.py:150-153 pads to a multiple of 2^6), level k of it (Tp_b >> k) rows of pitch 128 >> k;
+    the vocoder sees Tc_b = T_b + T_b % 2 + 4 frames (vocoder/base.py:40-47) and 441 * Tc_b samples."""
+
+    VOC_MULTS = (1, 7, 49, 147, 441)
+
+    def __init__(self, lengths, device):
+        n = torch.as_tensor(list(lengths), dtype=torch.int64)
+        T = 1 + n // 441
+        Tp = (T + 63) // 64 * 64
+        Tc = T + T % 2 + 4
+        table = [n, T] + [(Tp >> k) << (7 - k) for k in range(7)] + [Tc * m for m in self.VOC_MULTS]
+        dev = torch.stack(table).to(torch.int32).to(device)
+        self.n, self.T = dev[0], dev[1]
+        self.unet = [dev[2 + k] for k in range(7)]          # valid elements of a level-k pitch map, per row
+        self.voc = {int(m): dev[9 + i] for i, m in enumerate(self.VOC_MULTS)}   # upsampling factor -> valid length
+        self.T_max, self.n_max = int(T.max()), int(n.max())
+        self.B = len(n)
 
 
 def _dev(t, device):
@@ -113,12 +140,14 @@ class VocoderEngine:
             self._w3[key] = None if p is None else p.to(w.device)
         return self._w3[key]
 
-    def forward_cond(self, cond, Tc, stages=None):
-        """cond: device (B,128,>=Tc) channel-major.  Returns (wav buffer (B,1,Lp), L = 441*Tc)."""
+    def forward_cond(self, cond, Tc, stages=None, ragged=None):
+        """cond: device (B,128,>=Tc) channel-major.  Returns (wav buffer (B,1,Lp), L = 441*Tc).
+        ``ragged`` (RaggedRows): Tc is the largest row, row b has ragged.voc[1][b] valid frames."""
         B = cond.shape[0]
         dev = cond.device
-        a = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev)
-        b = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev)
+        rows = (lambda mult: ragged.voc[mult]) if ragged is not None else (lambda mult: None)
+        a = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev, rows(1))
+        b = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev, rows(1))
         x = cond
         for i, (w, wd, bias) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
@@ -127,20 +156,22 @@ class VocoderEngine:
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
         # pre: ReflectionPad1d(3) + Conv1d k7 + LeakyReLU(0.2); the next UpsampleNet's x+sin(x) is fused here
-        h = _rows(B, weights.VOC_CHANNELS, Tc, G_TILE, dev)
+        h = _rows(B, weights.VOC_CHANNELS, Tc, G_TILE, dev, rows(1))
         ops.conv1d(x, self.pre[0], self.pre[1], h, Tc, 7, 1, PAD_REFLECT, self.act_pre)
         L = Tc
         c = weights.VOC_CHANNELS
         nst = len(self.stages)
+        mult = 1
         for j, (s, upw, layers) in enumerate(self.stages):
             Lo = L * s
             c //= 2
+            mult *= s
             # (the fused kernel addresses one batch item with 32-bit byte offsets: rows of more than ~3 minutes at the last
             # stage fall back to the two-launch form, whose first-generation kernel has no such limit)
             fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and
                      c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
-            xs = _rows(B, c, Lo, G_DIL, dev)
-            ys = _rows(B, c, Lo, G_DIL if fused else G_TILE, dev)
+            xs = _rows(B, c, Lo, G_DIL, dev, rows(mult))
+            ys = _rows(B, c, Lo, G_DIL if fused else G_TILE, dev, rows(mult))
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
@@ -166,13 +197,18 @@ class VocoderEngine:
         ops.conv1d_cout1(h, self.post[0], self.post[1], wav, L, 7, PAD_REFLECT, POST_TANH)
         return wav, L
 
-    def forward(self, mel, T):
-        """mel: device (B,T,128) linear, non-normalised (Vocoder.forward semantics)."""
+    def forward(self, mel, T, ragged=None):
+        """mel: device (B,T,128) linear, non-normalised (Vocoder.forward semantics); ``ragged``: row b holds
+        ragged.T[b] <= T frames."""
         B = mel.shape[0]
         Tc = T + T % 2 + 4
-        cond = _rows(B, weights.N_MELS, Tc, G_TILE, mel.device)
-        ops.mel_to_cond(mel, cond, T)
-        return self.forward_cond(cond, Tc)
+        if ragged is None:
+            cond = _rows(B, weights.N_MELS, Tc, G_TILE, mel.device)
+            ops.mel_to_cond(mel, cond, T)
+            return self.forward_cond(cond, Tc)
+        cond = _rows(B, weights.N_MELS, Tc, G_TILE, mel.device, ragged.voc[1])
+        ops.mel_to_cond(mel, cond, T, ragged.T)
+        return self.forward_cond(cond, Tc, ragged=ragged)
 
 
 class _ConvBlock:
@@ -303,8 +339,10 @@ class RestorerEngine:
                        _dev(sd["unet.after_conv2.bias"], device))
 
     # -- denoiser -------------------------------------------------------------------
-    def denoiser(self, mel, T):
-        """mel (B,T,128) -> mask channel-major (B,128,Tp4)."""
+    def denoiser(self, mel, T, t_rows=None):
+        """mel (B,T,128) -> mask channel-major (B,128,Tp4).  ``t_rows`` (device int32 (B,)): frames of every row of a
+        ragged batch -- only the recurrence sees them (the reverse direction starts at each row's own last frame), the
+        linear layers are frame-wise."""
         B, dev = mel.shape[0], mel.device
         Tp4 = _up4(T)
         x0 = _rows(B, 128, T, G_TILE, dev)
@@ -327,6 +365,8 @@ class RestorerEngine:
                     b1 = min(B, b0 + self.gru_group)
                     yv = y[b0:b1]
                     yv._vfx_guard = getattr(y, "_vfx_guard", 0)
+                    if t_rows is not None:
+                        ops.with_rows(yv, t_rows[b0:b1])
                     keep.append(ops.gru_bidir2(gi[b0:b1], whh_t, bhh, yv, T, self.gru_err))
                 x = y
         self._gru_keep = keep  # mailboxes stay referenced until the next forward
@@ -334,6 +374,8 @@ class RestorerEngine:
         ops.conv1d(x, self.l3[0], self.l3[1], x3, T, 1, act=self.act_l3)
         mask = torch.empty((B, 128, Tp4), device=dev)
         ops.conv1d(x3, self.l4[0], self.l4[1], mask, T, 1, act=self.act_sigmoid)
+        if t_rows is not None:
+            ops.with_rows(mask, t_rows)
         return mask
 
     def set_math(self, math):
@@ -346,9 +388,11 @@ class RestorerEngine:
                 blk.set_math(math)
 
     # -- ResUNet ---------------------------------------------------------------------
-    def unet(self, u, Tp):
-        """u (B,2,Tp*128) pitch map -> (B,1,Tp*128)."""
+    def unet(self, u, Tp, ragged=None):
+        """u (B,2,Tp*128) pitch map -> (B,1,Tp*128).  ``ragged``: row b is a map of ragged.unet[0][b] / 128 <= Tp rows;
+        every 3x3 convolution zero-pads below the row's own last map row, exactly as it does for the utterance alone."""
         B, dev = u.shape[0], u.device
+        lv = (lambda lp: ragged.unet[7 - lp]) if ragged is not None else (lambda lp: None)
         x = u
         cats = []
         H, lp = Tp, 7
@@ -356,21 +400,21 @@ class RestorerEngine:
             cout = blocks[0].cout
             HP = H << lp
             G = (1 << lp) + 1 + G_TILE
-            cat = _rows(B, 2 * cout, HP, G, dev)
+            cat = _rows(B, 2 * cout, HP, G, dev, lv(lp))
             skip = cat[:, cout:]
-            a = _rows(B, cout, HP, G, dev)
-            y1 = _rows(B, cout, HP, G, dev)
+            a = _rows(B, cout, HP, G, dev, lv(lp))
+            y1 = _rows(B, cout, HP, G, dev, lv(lp))
             blocks[0].run(x, y1, a, H, lp)
             blocks[1].run(a, y1, a, H, lp)
             blocks[2].run(a, y1, a, H, lp)
             blocks[3].run(a, y1, skip, H, lp)
             cats.append((cat, H, lp))
-            pooled = _rows(B, cout, (H // 2) << (lp - 1), (1 << (lp - 1)) + 1 + G_TILE, dev)
+            pooled = _rows(B, cout, (H // 2) << (lp - 1), (1 << (lp - 1)) + 1 + G_TILE, dev, lv(lp - 1))
             ops.avgpool2x2(skip, pooled, H, lp)
             x = pooled
             H //= 2
             lp -= 1
-        y1 = _rows(B, x.shape[1], H << lp, (1 << lp) + 1 + G_TILE, dev)
+        y1 = _rows(B, x.shape[1], H << lp, (1 << lp) + 1 + G_TILE, dev, lv(lp))
         self.center.run(x, y1, x, H, lp)
         for (wt, act, blocks) in self.dec:
             cat, Hs, lps = cats.pop()
@@ -380,8 +424,8 @@ class RestorerEngine:
             H, lp = Hs, lps
             HP = H << lp
             G = (1 << lp) + 1 + G_TILE
-            a = _rows(B, cout, HP, G, dev)
-            y1 = _rows(B, cout, HP, G, dev)
+            a = _rows(B, cout, HP, G, dev, lv(lp))
+            y1 = _rows(B, cout, HP, G, dev, lv(lp))
             blocks[0].run(cat, y1, a, H, lp)
             for blk in blocks[1:]:
                 blk.run(a, y1, a, H, lp)
@@ -391,13 +435,16 @@ class RestorerEngine:
         ops.conv1d_cout1(x, self.after2[0], self.after2[1], out, H << lp, 1, PAD_ZERO, POST_NONE, lp)
         return out
 
-    def forward(self, mel, T, debug=None):
+    def forward(self, mel, T, debug=None, ragged=None):
+        """``ragged`` (RaggedRows): row b of mel holds ragged.T[b] <= T frames; rows of logmel / denoised are valid up
+        to their own frame count."""
         B, dev = mel.shape[0], mel.device
         Tp = (T + 63) // 64 * 64
-        mask = self.denoiser(mel, T)
-        u = _rows(B, 8, Tp * 128, 128 + 1 + G_TILE, dev)  # 2 real + 6 zero channels: no channel tail
+        mask = self.denoiser(mel, T, None if ragged is None else ragged.T)
+        u = _rows(B, 8, Tp * 128, 128 + 1 + G_TILE, dev,  # 2 real + 6 zero channels: no channel tail
+                  None if ragged is None else ragged.unet[0])
         ops.unet_input(mel, mask, u, T, Tp)
-        uo = self.unet(u, Tp)
+        uo = self.unet(u, Tp, ragged)
         logmel = torch.empty((B, T, 128), device=dev)
         den = torch.empty((B, T, 128), device=dev)
         ops.unet_output(uo, u, mel, mask, logmel, den, T, Tp)
@@ -498,24 +545,31 @@ class Pipeline:
             return static_out.clone()
         return self._restore_eager(wav, N, vocoder_func)
 
-    def restore_rows(self, wav, lengths):
-        """Utterances of DIFFERENT sample counts that share one frame count T = 1 + n // 441, as one batch:
-        wav device float32 (B, >= max(lengths)), lengths a list of ints.  Only the STFT (reflect padding at each row's
-        end) and the final centre trim see the sample count; restorer and vocoder depend on T alone, so every row
-        equals what ``restore`` returns for that utterance alone.  Returns device (B, max(lengths)); row b is valid up
-        to lengths[b] (zero beyond)."""
-        T = 1 + lengths[0] // 441
-        if any(1 + n // 441 != T for n in lengths) or min(lengths) < 1025:
-            raise VfxError("restore_rows needs rows of one frame count (1 + n // 441) and n >= 1025")
-        B, n_max = wav.shape[0], max(lengths)
-        n_rows = torch.tensor(lengths, dtype=torch.int32, device=wav.device)
+    def restore_rows(self, wav, lengths, force_ragged=False):
+        """A RAGGED batch: utterances of different sample counts in one launch sequence.  wav device float32
+        (B, >= max(lengths)), lengths a list of ints (each >= 1025).  Every kernel whose result depends on where a
+        sequence ends takes the per-row lengths (RaggedRows): the STFT reflects at each row's end, the GRU's reverse
+        direction starts at each row's last frame, every convolution zero- or reflect-pads at the row's own end (and
+        skips the tiles past it), the peak rule and the centre trim work on the row's own samples -- so row b equals
+        what ``restore`` returns for that utterance alone (same arithmetic; tile shapes may differ with the batch
+        size, which moves fp32 sums by ~1e-7).  Returns device (B, max(lengths)); row b is valid up to lengths[b]
+        (zero beyond).  Equal lengths take the plain batched path unless ``force_ragged`` (tests)."""
+        if min(lengths) < 1025:
+            raise VfxError("segment of %d samples is too short for the reflect-padded STFT (needs > 1024)" % min(lengths))
+        B = wav.shape[0]
+        if len(lengths) != B:
+            raise VfxError("restore_rows: %d lengths for %d rows" % (len(lengths), B))
+        if min(lengths) == max(lengths) and not force_ragged:
+            return self._restore_eager(wav, lengths[0])
+        rg = RaggedRows(lengths, wav.device)
+        T = rg.T_max
         mel = torch.empty((B, T, 128), device=wav.device)
-        ops.stft_mel_rows(wav, mel, n_rows, T)
-        _, den = self.restorer.forward(mel, T)
-        y, Ly = self.vocoder.forward(den, T)
-        out = torch.zeros((B, n_max), device=wav.device)
+        ops.stft_mel_rows(wav, mel, rg.n, T)
+        _, den = self.restorer.forward(mel, T, ragged=rg)
+        y, Ly = self.vocoder.forward(den, T, ragged=rg)
+        out = torch.zeros((B, rg.n_max), device=wav.device)
         ws = torch.empty((B,), dtype=torch.int32, device=wav.device)
-        ops.post_rows(y[:, 0], Ly, out, n_rows, n_max, ws)
+        ops.post_rows(y[:, 0], Ly, out, rg.n, rg.n_max, ws, ly_rows=rg.voc[441])
         return out
 
     def _restore_eager(self, wav, N, vocoder_func=None):

@@ -29,7 +29,17 @@ def tdesc(t):
     """vfx_tensor for a (B, C, L) tensor view (any strides; element units).  Views created by
     ``guarded()`` carry a ``_vfx_guard`` attribute: readable slack on both sides of every row."""
     assert t.dim() == 3 and t.dtype == torch.float32
-    return vfx_tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), getattr(t, "_vfx_guard", 0))
+    rows = getattr(t, "_vfx_rows", None)   # ragged batches: device int32 (B,) valid length per batch item
+    return vfx_tensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2), getattr(t, "_vfx_guard", 0),
+                      rows.data_ptr() if rows is not None else None)
+
+
+def with_rows(t, rows):
+    """Tag a (B, C, L) view with per-batch-item valid lengths (device int32 (B,)); None removes the tag."""
+    if rows is not None:
+        assert rows.dtype == torch.int32 and rows.is_cuda and rows.numel() == t.shape[0]
+    t._vfx_rows = rows
+    return t
 
 
 def guarded(B, Cn, L, guard, device):
@@ -346,18 +356,21 @@ def gru_bidir2(gi, whh_t, bhh, out, T, err_flag):
     return mbox  # keep alive until the stream has consumed it (caller holds the reference)
 
 
-def mel_to_cond(mel, cond, T):
-    _need_cuda(mel, cond)
+def mel_to_cond(mel, cond, T, t_rows=None):
+    """mel (B, T, 128) -> cond (B, 128, >= T'); t_rows (device int32 or None): frames of every row (ragged batches)."""
+    _need_cuda(mel, cond, t_rows)
     assert mel.is_contiguous()
     cd = tdesc(cond)
-    check(_lib.lib().vfx_mel_to_cond_f32(_ptr(mel), C.byref(cd), mel.shape[0], T, _stream()), "vfx_mel_to_cond_f32")
+    check(_lib.lib().vfx_mel_to_cond_rows_f32(_ptr(mel), C.byref(cd), mel.shape[0], T, _ptr(t_rows), 1, _stream()),
+          "vfx_mel_to_cond_rows_f32")
 
 
-def post_rows(y, Ly, out, n_rows, n_max, peak_ws):
-    """y (B, >=Ly) -> out (B, >= n_max): per-utterance peak rule + centre trim to n_rows[b] samples (device int32)."""
-    _need_cuda(y, out, peak_ws, n_rows)
-    check(_lib.lib().vfx_post_rows_f32(_ptr(y), y.stride(0), Ly, _ptr(out), out.stride(0), _ptr(n_rows), n_max,
-                                       y.shape[0], _ptr(peak_ws), _stream()), "vfx_post_rows_f32")
+def post_rows(y, Ly, out, n_rows, n_max, peak_ws, ly_rows=None):
+    """y (B, >=Ly) -> out (B, >= n_max): per-utterance peak rule + centre trim to n_rows[b] samples (device int32);
+    ly_rows (device int32 or None): vocoder samples of every row."""
+    _need_cuda(y, out, peak_ws, n_rows, ly_rows)
+    check(_lib.lib().vfx_post_rows_f32(_ptr(y), y.stride(0), Ly, _ptr(ly_rows), _ptr(out), out.stride(0), _ptr(n_rows),
+                                       n_max, y.shape[0], _ptr(peak_ws), _stream()), "vfx_post_rows_f32")
 
 
 def post(y, Ly, out, N, peak_ws):
