@@ -224,7 +224,8 @@ int vfx_tm_to_cm_f32(const float* src, float* dst, int B, int T, int C, int64_t 
 /* clean = mask*mel; x = log10(max(clean,1e-8)); U = [log10(max(mel,1e-8)), x] written as the
  * UNet input (B,nch>=2,Tp*128) pitch map (channels >= 2 are zero filler so the first conv has no
  * channel tail) with bin 127 and rows >= T zero.  mask is channel-major
- * (B,128,*).  Replaces voicefixer/restorer/model.py:105-108 + model_kqq_bn.py:145-151. */
+ * (B,128,*).  Ragged batches: mask->rows[b] = frames of row b (T is then the frame pitch of mel; rows from
+ * mask->rows[b] on are zero).  Replaces voicefixer/restorer/model.py:105-108 + model_kqq_bn.py:145-151. */
 int vfx_unet_input_f32(const float* mel, const vfx_tensor* mask, const vfx_tensor* unet_in, int nch,
                        int B, int T, int Tp, vfx_stream_t stream);
 
@@ -241,7 +242,8 @@ int vfx_unet_output_f32(const vfx_tensor* unet_out, const vfx_tensor* unet_in, c
  * whh_packed = W_hh of both directions in the layout of voicefixer_amd/packing.py::pack_gru_whh
  * (per direction: register-resident rows, LDS-resident rows, L2-streamed rows; the split is
  * reported by vfx_gru_layout).  bhh = [2][768].  out is channel-major (B,512,*): fwd in channels
- * 0..255, bwd in 256..511.
+ * 0..255, bwd in 256..511.  Ragged batches: out->rows[b] = frames of sequence b (T is then the frame pitch of gi; the
+ * reverse direction starts at frame rows[b]-1, frames >= rows[b] of out are not written); same for vfx_gru_bidir2_f32.
  * Replaces the recurrent part of torch.nn.GRU in voicefixer/restorer/model.py:37-44,57-62. */
 void vfx_gru_layout(int* kreg, int* klds, int* kstr);
 int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const float* bhh,

@@ -380,8 +380,8 @@ class VoiceFixer(nn.Module):
     def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
         ``infolder`` -> same file name in ``outfolder``), batched and pipelined: the lengths come from the WAV headers,
-        the length-sorted list is cut into windows of 8 batches, and while window k is restored on the device (exact-
-        length buckets of up to ``batch_size``) a thread pool decodes / resamples / down-mixes window k+1 and encodes
+        the length-sorted list is cut into windows of 8 batches, and while window k is restored on the device (ragged
+        batches of up to ``batch_size`` files, see restore_batch) a thread pool decodes / resamples / down-mixes window k+1 and encodes
         window k-1 to PCM16.  Host memory holds two windows at most.  Returns the list of file names written."""
         from concurrent.futures import ThreadPoolExecutor
         self._check_mode(mode)
