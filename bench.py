@@ -322,10 +322,18 @@ def main():
         if code in (61, 62, 64):
             return ("wfused", bm, bl), "convw_kernel<%d,%d,*,*,3,*,true> (fused ResStack layer)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, true>" % (bm, bl)
+        if code == 70:
+            return ("wino", bm, bl), "convwg_kernel<4,1> (Winograd F(2,3), 128 ch x 64 output pairs)", r"convwg_kernel<\d+, \d+>"
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
                r"conv_taps_kernel<%d, %d, \d+, \d+, %d," % (bm, bl, code)
+
+    # Arithmetic a family EXECUTES per multiply-accumulate of the direct convolution: the Winograd F(2,3) kernel
+    # forms 4 products per pair of outputs where the direct sum has 6.  `achieved` / `frac` below count executed MFMA
+    # work (what the matrix pipe can be compared with); the direct-convolution equivalent is reported next to it.
+    def exec_factor(key):
+        return 2.0 / 3.0 if key[0] == "wino" else 1.0
 
     by_fam = {}
     stft_bytes, stft_secs, stft_n = 0, 0.0, 0
@@ -336,14 +344,15 @@ def main():
             stft_n += 1
             continue
         key, name, rx = family(tile)
-        d = by_fam.setdefault(key, [0, 0, 0.0, name, rx])
+        d = by_fam.setdefault(key, [0, 0, 0.0, name, rx, exec_factor(key)])
         d[0] += 1
         d[1] += macs
         d[2] += e0.elapsed_time(e1) * 1e-3
     conv_time = sum(d[2] for d in by_fam.values())
-    conv_macs = sum(d[1] for d in by_fam.values())
-    launches, macs, secs, kname, krx = max(by_fam.values(), key=lambda d: d[2])
-    achieved = 2.0 * macs / secs / 1e12
+    conv_macs = sum(d[1] * d[5] for d in by_fam.values())
+    conv_macs_direct = sum(d[1] for d in by_fam.values())
+    launches, macs, secs, kname, krx, xf = max(by_fam.values(), key=lambda d: d[2])
+    achieved = 2.0 * macs * xf / secs / 1e12
     # HBM bytes per launch of that family: PMC counters cannot be read live; they come from the committed rocprofv3
     # --pmc passes over this same command (tools/profile_round.sh -> profiles/r02_pmc_hbm_traffic_bench_b32.json)
     traffic = None
@@ -366,13 +375,20 @@ def main():
         "kernel": kname, "kernel_name_regex": krx,
         "launches_per_step": launches // args.steps,
         "avg_launch_ms": round(secs / launches * 1e3, 4),
-        "algorithmic_gflop_per_launch": round(2.0 * macs / launches / 1e9, 3),
+        "algorithmic_gflop_per_launch": round(2.0 * macs * xf / launches / 1e9, 3),
         "all_conv_kernels": {"achieved": round(2.0 * conv_macs / conv_time / 1e12, 2),
+                             "direct_equivalent": round(2.0 * conv_macs_direct / conv_time / 1e12, 2),
                              "time_share_of_step": round(conv_time / dt, 4) if world == 1 else None},
         "families": {d[3]: {"launches_per_step": d[0] // args.steps, "ms_per_step": round(d[2] / args.steps * 1e3, 2),
-                            "tflops": round(2.0 * d[1] / d[2] / 1e12, 1)}
+                            "tflops": round(2.0 * d[1] * d[5] / d[2] / 1e12, 1),
+                            **({"direct_equivalent_tflops": round(2.0 * d[1] / d[2] / 1e12, 1)} if d[5] != 1.0 else {})}
                      for d in sorted(by_fam.values(), key=lambda d: -d[2])[:8]},
     }
+    if xf != 1.0:
+        roofline["algorithm"] = ("Winograd F(2,3) along the dilated axis: 4 fp32 MFMA products per output pair instead "
+                                 "of 6; achieved / frac / algorithmic_gflop_per_launch count the EXECUTED products")
+        roofline["direct_conv_gflop_per_launch"] = round(2.0 * macs / launches / 1e9, 3)
+        roofline["direct_equivalent_tflops"] = round(2.0 * macs / secs / 1e12, 2)
 
     if stft_n:
         # reported for completeness: the front-end moves the algorithmic minimum of bytes

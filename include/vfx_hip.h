@@ -90,6 +90,12 @@ typedef struct {
                                on convw_kernel (weights read from L2 as MFMA A-operand vectors, activations staged
                                16-32 channels deep); bit-identical results are NOT implied (other summation order
                                within fp32 rounding).  Everything else, and small launches, use w_packed. */
+    const float* w_wino;    /* optional (may be NULL), k = 3 stride-1 Conv1d only: the Winograd F(2,3) transform of
+                               the three tap slabs, U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2, packed
+                               like w_direct with 4 slabs (packing.py::pack_wino).  Large launches with Cin % 32 == 0,
+                               Cout % 128 == 0, zero padding and no BatchNorm pre-activation then run on convwg_kernel:
+                               two outputs a dilation apart share four products instead of six (1.5x fewer fp32 MFMAs;
+                               the result differs from the direct sum by fp32 rounding only). */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0

@@ -263,6 +263,92 @@ def test_conv1d_convw(case):
         _close(rd2[:, :, :L], ref, 2e-5)
 
 
+WINO_CASES = [
+    # B, Cin, Cout, L, dil, pre, post, res   (k = 3; >= 512 workgroups of 128 channels x 64 pairs -> convwg_kernel)
+    (8, 256, 256, 4100, 1, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (8, 256, 256, 4099, 1, _lib.PRE_NONE, _lib.POST_NONE, True),       # odd length: the last pair has one output
+    (8, 256, 256, 4100, 3, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (8, 256, 128, 9001, 9, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (8, 128, 256, 4100, 27, _lib.PRE_LRELU, _lib.POST_LRELU_SNAKE, True),
+    (8, 256, 256, 4100, 81, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (8, 256, 256, 4100, 243, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (8, 256, 256, 4100, 729, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (8, 256, 256, 4100, 2187, _lib.PRE_LRELU, _lib.POST_NONE, True),   # 2d > L: every pair has one output
+    (4, 512, 512, 4200, 81, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (16, 32, 128, 4000, 1, _lib.PRE_NONE, _lib.POST_ELU, False),       # Cin = 32: two chunks
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv1d_winograd(case):
+    """convwg_kernel (vfx_act.w_wino): the k = 3 Conv1d as Winograd F(2,3) along the dilated axis -- four fp32 MFMA
+    products per output pair instead of six.  Against torch's direct fp32 conv1d at the tolerance of the direct
+    kernels; also no guard band is needed (taps outside the row are dropped by the buffer unit), nothing is written
+    past L, and the in-place residual update works."""
+    B, Cin, Cout, L, dil, pre, post, use_res = case
+    x = _rand((B, Cin, L), 161)
+    w = _rand((Cout, Cin, 3), 162, (Cin * 3) ** -0.5)
+    bias = _rand((Cout,), 163, 0.1)
+    res = _rand((B, Cout, L), 164) if use_res else None
+    ref = F.conv1d(_ref_act(x, pre, 0.01), w, bias, dilation=dil, padding=dil)
+    if use_res:
+        ref = ref + res
+    ref = _ref_post(ref, post, 0.2)
+    lp = (L + 67) // 4 * 4
+    xd = torch.full((B, Cin, lp), float("nan"), device=DEV)     # NO guard band; NaN right after the row
+    xd[:, :, :L] = x.to(DEV)
+    yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+    rd = _padded(res, lp) if use_res else None
+    act = ops.Act(pre=pre, pre_slope=0.01, post=post, post_slope=0.2)
+    wp = packing.pack_conv1d(w)
+    wg = packing.pack_wino(wp).to(DEV)
+    before = _lib.lib().vfx_launch_count()
+    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, rd, wg=wg)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 70, "launch did not run on convwg_kernel"
+    _close(yd[:, :, :L], ref, 2e-5)
+    assert torch.isnan(yd[:, :, L:]).all()
+    if use_res and post == _lib.POST_NONE:
+        rd2 = _padded(res, lp)   # in-place residual update (the engine's pattern for the unfused stages)
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), rd2, L, 3, dil, 0, act, rd2, wg=wg)
+        torch.cuda.synchronize()
+        _close(rd2[:, :, :L], ref, 2e-5)
+
+
+def test_conv1d_winograd_ragged_rows_and_fallback():
+    """Per-row lengths: every row of a ragged launch equals the same row convolved alone (zero padding at ITS end);
+    small launches and shapes the kernel does not cover fall back to the direct kernels with the same result."""
+    B, C, L, dil = 8, 256, 4100, 27
+    lens = [4100, 4099, 2050, 2051, 3000, 54, 4047, 1]
+    x = _rand((B, C, L), 171)
+    w = _rand((C, C, 3), 172, (C * 3) ** -0.5)
+    bias = _rand((C,), 173, 0.1)
+    wp = packing.pack_conv1d(w)
+    wg = packing.pack_wino(wp).to(DEV)
+    act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01)
+    xd = _guarded_nan(x, 8)
+    yd = torch.full((B, C, L + 60), float("nan"), device=DEV)
+    ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
+    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg=wg)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 70
+    for r, n in enumerate(lens):
+        ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
+        _close(yd[r:r + 1, :, :n], ref, 2e-5)
+        assert torch.isnan(yd[r, :, n:]).all()      # nothing is written past a row's own length
+    # fallbacks: a launch too small for the big tile, and Cout = 64
+    for (b2, cin, cout, l2) in ((1, 256, 256, 900), (8, 64, 64, 4000)):
+        x2 = _rand((b2, cin, l2), 174)
+        w2 = _rand((cout, cin, 3), 175, (cin * 3) ** -0.5)
+        wp2 = packing.pack_conv1d(w2)
+        y2 = torch.full((b2, cout, l2 + 4), float("nan"), device=DEV)
+        ops.conv1d(_guarded_nan(x2, 300), wp2.to(DEV), None, y2, l2, 3, 3, 0, None, None, wg=packing.pack_wino(wp2).to(DEV))
+        torch.cuda.synchronize()
+        assert _lib.lib().vfx_last_conv_tile() % 100 != 70
+        _close(y2[:, :, :l2], F.conv1d(x2, w2, None, dilation=3, padding=3), 2e-5)
+
+
 @pytest.mark.parametrize("cfg", [(4, 256, 128, 5000, 3), (2, 512, 256, 2000, 7), (8, 128, 64, 6000, 3)])
 def test_convtr1d_convw(cfg):
     B, Cin, Cout, Lin, s = cfg

@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--x3", action="store_true", help="VFX_MATH_BF16X3 (guarded inputs, 1-D shapes only)")
     ap.add_argument("--wd", action="store_true", help="offer the convw_kernel weight layout (vfx_act.w_direct)")
+    ap.add_argument("--wg", action="store_true", help="offer the Winograd F(2,3) weights (vfx_act.w_wino; k = 3 shapes); "
+                    "TFLOP/s stay the DIRECT algorithm's 2*MACs / time")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -87,7 +89,8 @@ def main():
             bias = torch.zeros(cout, device=dev)
             pad = 1 if kind == "c1r" else 0
             wd = packing.pack_direct(wp).to(dev) if args.wd else None
-            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd)
+            wg = packing.pack_wino(wp).to(dev) if (args.wg and k == 3) else None
+            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd, wg=wg)
             macs = B * L * cin * cout * k
         elif kind == "rb":
             x = ops.guarded(B, cin, L, 2187 + 264, dev)

@@ -55,7 +55,7 @@ def _load_restorer_state(path):
     return out, (voc or None)  # vf.ckpt may overwrite the vocoder weights
 
 
-def plan_batches(sorted_lengths, batch_size, ragged_ratio=0.75, ragged=True):
+def plan_batches(sorted_lengths, batch_size, ragged_ratio=0.5, ragged=True):
     """Cut a list of ASCENDING sample counts into batches: ("ragged", [positions]) for runs of utterances of
     1025..SEG_LENGTH samples whose shortest member has >= ragged_ratio of the frames (1 + n // 441) of the longest
     (Pipeline.restore_rows), ("samples", [positions]) for runs of exactly equal length otherwise (files of several
@@ -281,7 +281,7 @@ class VoiceFixer(nn.Module):
         return pipe.restore(seg, n, your_vocoder_func)
 
     @torch.no_grad()
-    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=2, ragged_ratio=0.75):
+    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=2, ragged_ratio=0.5):
         """Batched folder inference (not in the reference, which loops files at B=1,
         voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i).
         Utterances of up to 30 s go through RAGGED batches: the length-sorted list is cut into runs of up to

@@ -109,6 +109,7 @@ struct ConvArgs {
     const float* wd;        // weights packed [slab][Cin/8][Cout][8 channels in the order 0,2,4,6,1,3,5,7]
     int kcx;                // channels per activation chunk (8, 16 or 32)
     int ntiles_l, xcd_chunk;      // tiles along L; XCD-aware tile order: tiles per XCD (0 = linear order)
+    int wg_d;                     // convwg_kernel (Winograd F(2,3) along the dilated axis): the dilation
     const int* x_rows;            // ragged batches: valid input length of batch item b (device int32[B]) or NULL (= Lin)
     int lq_extra;                 // ... its valid output-position count is x_rows[b] + lq_extra (1 for transposed 1-D convs)
     int stagger, stagger_wgs;     // development: start stagger of the first residency round (s_sleep units, workgroups)
@@ -1184,6 +1185,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 #define VFX_ENOTSUP (-100)
 
 #include "vfx_convw.inc"
+#include "vfx_convwg.inc"
 
 template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS = 1>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -1383,6 +1385,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     if (act && act->math == VFX_MATH_BF16X3) {
         const int rc3 = try_launch_x3(a, x, nphase, phs, act->w_x3, stream);
         if (rc3 != VFX_ENOTSUP) return rc3;
+    }
+    if (act && act->w_wino) {
+        const int rcg = try_launch_convwg(a, x, nphase, phs, act->w_wino, stream);
+        if (rcg != VFX_ENOTSUP) return rcg;
     }
     if (act && act->w_direct) {
         int rcw = VFX_ENOTSUP;

@@ -81,7 +81,12 @@ import os as _os
 # development switches: VFX_FUSE=0 runs every ResStack layer as two launches, VFX_CONVW=0 (read by the library)
 # keeps every launch on the first-generation kernel
 _FUSE = _os.environ.get("VFX_FUSE", "1") != "0"
-FUSE_MAX_C = 128  # ResStack stages with at most this many channels run one fused launch per layer
+FUSE_MAX_C = 128  # ResStack stages with at most this many channels can run one fused launch per layer
+# ResStack stages with at least this many channels run their k = 3 convolutions on the Winograd F(2,3) kernel
+# (convwg_kernel: 1.5x fewer fp32 MFMAs; needs Cout % 128 == 0).  Measured per layer at batch 32: C = 128 as two
+# Winograd launches 6.1 ms against 7.4 ms for the fused direct layer, so the fused form is kept for C = 64 only.
+# VFX_WINO_MIN_C=0 disables (development).
+WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 
 
 class VocoderEngine:
@@ -108,11 +113,16 @@ class VocoderEngine:
             rs = "generator.%d" % (4 + 3 * j)
             upw = _wpair(packing.pack_convtr1d(wn(up)), device) + (_dev(sd[up + ".bias"], device),)
             layers = []
+            cst = weights.VOC_CHANNELS >> (j + 1)
+            wino = WINO_MIN_C > 0 and cst >= WINO_MIN_C and cst % 128 == 0
             for i in range(weights.RESSTACK_DEPTH):
                 a = "%s.layers.%d.1" % (rs, i)
                 b = "%s.layers.%d.3" % (rs, i)
-                layers.append(_wpair(packing.pack_conv1d(wn(a)), device) + (_dev(sd[a + ".bias"], device),) +
-                              _wpair(packing.pack_conv1d(wn(b)), device) + (_dev(sd[b + ".bias"], device),))
+                wa, wb = packing.pack_conv1d(wn(a)), packing.pack_conv1d(wn(b))
+                layers.append(_wpair(wa, device) + (_dev(sd[a + ".bias"], device),) +
+                              _wpair(wb, device) + (_dev(sd[b + ".bias"], device),) +
+                              ((_dev(packing.pack_wino(wa), device), _dev(packing.pack_wino(wb), device)) if wino
+                               else (None, None)))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -168,14 +178,15 @@ class VocoderEngine:
             mult *= s
             # (the fused kernel addresses one batch item with 32-bit byte offsets: rows of more than ~3 minutes at the last
             # stage fall back to the two-launch form, whose first-generation kernel has no such limit)
-            fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and
+            wino = layers[0][6] is not None and self.math == "f32"
+            fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and not wino and
                      c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
             xs = _rows(B, c, Lo, G_DIL, dev, rows(mult))
             ys = _rows(B, c, Lo, G_DIL if fused else G_TILE, dev, rows(mult))
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
-            for i, (w1, w1d, b1, w2, w2d, b2) in enumerate(layers):
+            for i, (w1, w1d, b1, w2, w2d, b2, w1g, w2g) in enumerate(layers):
                 last = i == len(layers) - 1
                 if fused:
                     # one launch per layer, intermediate tile in LDS; input and output ping-pong between xs and ys
@@ -186,9 +197,11 @@ class VocoderEngine:
                     src, dst = (xs, ys) if i % 2 == 0 else (ys, xs)
                     ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope)
                     continue
-                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d)
+                if not wino:
+                    w1g = w2g = None
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg=w1g)
                 act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
-                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d)  # residual updated in place
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg=w2g)  # residual updated in place
             assert len(layers) % 2 == 0  # the fused ping-pong ends in xs
             h = xs
             L = Lo
