@@ -323,7 +323,9 @@ def main():
             return ("wfused", bm, bl), "convw_kernel<%d,%d,*,*,3,*,true> (fused ResStack layer)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, true>" % (bm, bl)
         if code == 70:
-            return ("wino", bm, bl), "convwg_kernel<4,1> (Winograd F(2,3), 128 ch x 64 output pairs)", r"convwg_kernel<\d+, \d+>"
+            wgm = bm // 32
+            return ("wino", bm, bl), "convwg_kernel<%d,%d,*> (Winograd F(2,3), %d ch x %d output pairs)" % (
+                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d, (true|false)>" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \

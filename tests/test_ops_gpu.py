@@ -276,6 +276,10 @@ WINO_CASES = [
     (8, 256, 256, 4100, 2187, _lib.PRE_LRELU, _lib.POST_NONE, True),   # 2d > L: every pair has one output
     (4, 512, 512, 4200, 81, _lib.PRE_LRELU, _lib.POST_LRELU, False),
     (16, 32, 128, 4000, 1, _lib.PRE_NONE, _lib.POST_ELU, False),       # Cin = 32: two chunks
+    (8, 64, 64, 17001, 1, _lib.PRE_LRELU, _lib.POST_NONE, True),       # Cout = 64: 64 channels x 128 pairs per workgroup
+    (8, 64, 64, 18000, 27, _lib.PRE_LRELU, _lib.POST_LRELU, False),
+    (8, 128, 64, 18000, 2187, _lib.PRE_LRELU, _lib.POST_NONE, True),
+    (8, 64, 192, 8000, 81, _lib.PRE_LRELU, _lib.POST_LRELU, False),
 ]
 
 
@@ -314,12 +318,26 @@ def test_conv1d_winograd(case):
         ops.conv1d(xd, wp.to(DEV), bias.to(DEV), rd2, L, 3, dil, 0, act, rd2, wg=wg)
         torch.cuda.synchronize()
         _close(rd2[:, :, :L], ref, 2e-5)
+    if dil == 1:
+        # with a guard band dilation 1 takes the contiguous-tap instance (one 16-byte load per pair and channel,
+        # 8-byte residual loads / stores; the vector of an edge pair reaches into the guard: NaN there must not leak)
+        xg = _guarded_nan(x, 8)
+        yd2 = torch.full((B, Cout, lp), float("nan"), device=DEV)
+        os.environ["VFX_WINO_D1"] = "1"            # (opt-in instance, the switch is read per launch)
+        try:
+            ops.conv1d(xg, wp.to(DEV), bias.to(DEV), yd2, L, 3, dil, 0, act, _padded(res, lp) if use_res else None, wg=wg)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["VFX_WINO_D1"]
+        assert _lib.lib().vfx_last_conv_tile() % 100 == 70
+        _close(yd2[:, :, :L], ref, 2e-5)
+        assert torch.isnan(yd2[:, :, L:]).all()
 
 
 def test_conv1d_winograd_ragged_rows_and_fallback():
     """Per-row lengths: every row of a ragged launch equals the same row convolved alone (zero padding at ITS end);
     small launches and shapes the kernel does not cover fall back to the direct kernels with the same result."""
-    B, C, L, dil = 8, 256, 4100, 27
+    B, C, L = 8, 256, 4100
     lens = [4100, 4099, 2050, 2051, 3000, 54, 4047, 1]
     x = _rand((B, C, L), 171)
     w = _rand((C, C, 3), 172, (C * 3) ** -0.5)
@@ -327,18 +345,24 @@ def test_conv1d_winograd_ragged_rows_and_fallback():
     wp = packing.pack_conv1d(w)
     wg = packing.pack_wino(wp).to(DEV)
     act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01)
-    xd = _guarded_nan(x, 8)
-    yd = torch.full((B, C, L + 60), float("nan"), device=DEV)
-    ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
-    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg=wg)
-    torch.cuda.synchronize()
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 70
-    for r, n in enumerate(lens):
-        ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
-        _close(yd[r:r + 1, :, :n], ref, 2e-5)
-        assert torch.isnan(yd[r, :, n:]).all()      # nothing is written past a row's own length
-    # fallbacks: a launch too small for the big tile, and Cout = 64
-    for (b2, cin, cout, l2) in ((1, 256, 256, 900), (8, 64, 64, 4000)):
+    for dil, d1 in ((27, False), (1, False), (1, True)):   # (d1: the opt-in contiguous-tap instance of dilation 1)
+        xd = _guarded_nan(x, 8)
+        yd = torch.full((B, C, L + 60), float("nan"), device=DEV)
+        ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
+        if d1:
+            os.environ["VFX_WINO_D1"] = "1"
+        try:
+            ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg=wg)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("VFX_WINO_D1", None)
+        assert _lib.lib().vfx_last_conv_tile() % 100 == 70
+        for r, n in enumerate(lens):
+            ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
+            _close(yd[r:r + 1, :, :n], ref, 2e-5)
+            assert torch.isnan(yd[r, :, n:]).all()      # nothing is written past a row's own length
+    # fallbacks: a launch too small for the big tile, and Cout = 96
+    for (b2, cin, cout, l2) in ((1, 256, 256, 900), (8, 64, 96, 4000)):
         x2 = _rand((b2, cin, l2), 174)
         w2 = _rand((cout, cin, 3), 175, (cin * 3) ** -0.5)
         wp2 = packing.pack_conv1d(w2)

@@ -83,9 +83,10 @@ import os as _os
 _FUSE = _os.environ.get("VFX_FUSE", "1") != "0"
 FUSE_MAX_C = 128  # ResStack stages with at most this many channels can run one fused launch per layer
 # ResStack stages with at least this many channels run their k = 3 convolutions on the Winograd F(2,3) kernel
-# (convwg_kernel: 1.5x fewer fp32 MFMAs; needs Cout % 128 == 0).  Measured per layer at batch 32: C = 128 as two
-# Winograd launches 6.1 ms against 7.4 ms for the fused direct layer, so the fused form is kept for C = 64 only.
-# VFX_WINO_MIN_C=0 disables (development).
+# (convwg_kernel: 1.5x fewer fp32 MFMAs; needs Cout % 64 == 0).  Measured per layer at batch 32, two Winograd launches
+# against the fused direct layer (vfx_resblock_f32): C = 128 5.9 ms against 7.4 ms; C = 64 7.2 ms against 6.3 ms (the
+# second launch reads the intermediate AND the residual from HBM: 10.9 GB, bandwidth-bound) -- so the C = 64 stage
+# keeps the fused layer.  VFX_WINO_MIN_C=64 / 0: development switch.
 WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 
 
@@ -114,7 +115,7 @@ class VocoderEngine:
             upw = _wpair(packing.pack_convtr1d(wn(up)), device) + (_dev(sd[up + ".bias"], device),)
             layers = []
             cst = weights.VOC_CHANNELS >> (j + 1)
-            wino = WINO_MIN_C > 0 and cst >= WINO_MIN_C and cst % 128 == 0
+            wino = WINO_MIN_C > 0 and cst >= WINO_MIN_C and cst % 64 == 0
             for i in range(weights.RESSTACK_DEPTH):
                 a = "%s.layers.%d.1" % (rs, i)
                 b = "%s.layers.%d.3" % (rs, i)
