@@ -307,6 +307,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 16: conv_x3_kernel,
+    # 70 / 79: convwg_kernel (Winograd F(2,3): 1-D / 3x3 on pitch maps),
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
     import re
@@ -322,10 +323,13 @@ def main():
         if code in (61, 62, 64):
             return ("wfused", bm, bl), "convw_kernel<%d,%d,*,*,3,*,true> (fused ResStack layer)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, true>" % (bm, bl)
-        if code == 70:
+        if code in (70, 79):
             wgm = bm // 32
-            return ("wino", bm, bl), "convwg_kernel<%d,%d,*> (Winograd F(2,3), %d ch x %d output pairs)" % (
-                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d, (true|false)>" % (wgm, 4 // wgm)
+            if code == 79:
+                return ("wino2d", bm, bl), "convwg_kernel<%d,%d,false,3> (3x3 as Winograd F(2,3) along the map rows)" % (
+                    wgm, 4 // wgm), r"convwg_kernel<%d, %d, false, 3>" % (wgm, 4 // wgm)
+            return ("wino", bm, bl), "convwg_kernel<%d,%d,*,1> (Winograd F(2,3), %d ch x %d output pairs)" % (
+                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d, (true|false), 1>" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
@@ -335,7 +339,7 @@ def main():
     # forms 4 products per pair of outputs where the direct sum has 6.  `achieved` / `frac` below count executed MFMA
     # work (what the matrix pipe can be compared with); the direct-convolution equivalent is reported next to it.
     def exec_factor(key):
-        return 2.0 / 3.0 if key[0] == "wino" else 1.0
+        return 2.0 / 3.0 if key[0] in ("wino", "wino2d") else 1.0
 
     by_fam = {}
     stft_bytes, stft_secs, stft_n = 0, 0.0, 0

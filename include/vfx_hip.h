@@ -95,7 +95,9 @@ typedef struct {
                                like w_direct with 4 slabs (packing.py::pack_wino).  Large launches with Cin % 32 == 0,
                                Cout % 128 == 0, zero padding and no BatchNorm pre-activation then run on convwg_kernel:
                                two outputs a dilation apart share four products instead of six (1.5x fewer fp32 MFMAs;
-                               the result differs from the direct sum by fp32 rounding only). */
+                               the result differs from the direct sum by fp32 rounding only).  For vfx_conv2d_f32 with
+                               ksize 3: the transform along the kernel's row axis for each kernel column, 12 slabs
+                               kx*4 + plane (packing.py::pack_wino2d); Cout % 64 == 0, Cin % 32 == 0, a guard band. */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0

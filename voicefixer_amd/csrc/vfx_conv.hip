@@ -1387,7 +1387,15 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         if (rc3 != VFX_ENOTSUP) return rc3;
     }
     if (act && act->w_wino) {
-        const int rcg = try_launch_convwg(a, x, nphase, phs, act->w_wino, stream);
+        int rcg = VFX_ENOTSUP;
+        if (nphase == 1 && phs[0].ntaps == 9 && in_mask > 0) {
+            const int P = in_mask + 1;
+            bool ok = true;
+            for (int t = 0; t < 9; ++t) ok &= phs[0].taps[t].off == (t / 3 - 1) * P + (t % 3 - 1) && phs[0].taps[t].slab == t;
+            if (ok) rcg = try_launch_convwg_2d(a, x, P, act->w_wino, stream);
+        } else {
+            rcg = try_launch_convwg(a, x, nphase, phs, act->w_wino, stream);
+        }
         if (rcg != VFX_ENOTSUP) return rcg;
     }
     if (act && act->w_direct) {

@@ -88,6 +88,7 @@ FUSE_MAX_C = 128  # ResStack stages with at most this many channels can run one 
 # second launch reads the intermediate AND the residual from HBM: 10.9 GB, bandwidth-bound) -- so the C = 64 stage
 # keeps the fused layer.  VFX_WINO_MIN_C=64 / 0: development switch.
 WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
+WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"   # the same for the 3x3 convolutions of the ResUNet (Cout % 64 == 0)
 
 
 class VocoderEngine:
@@ -240,9 +241,14 @@ class _ConvBlock:
             sh1 = torch.cat([sh1, torch.zeros(extra)])
             self.cin = pad_cin
         self.cout = w1.shape[0]
-        self.w1, self.w1d = _wpair(packing.pack_conv2d(w1), device)
+        wp1, wp2 = packing.pack_conv2d(w1), packing.pack_conv2d(sd[p + ".conv2.weight"])
+        self.w1, self.w1d = _wpair(wp1, device)
         self.b1 = _dev(sh2, device)
-        self.w2, self.w2d = _wpair(packing.pack_conv2d(sd[p + ".conv2.weight"]), device)
+        self.w2, self.w2d = _wpair(wp2, device)
+        # Winograd F(2,3) along the map rows (convwg_kernel, NKX = 3) where the kernel has an instance
+        wino = WINO2D and self.cout % 64 == 0
+        self.w1g = _dev(packing.pack_wino2d(wp1), device) if wino and self.cin % 32 == 0 else None
+        self.w2g = _dev(packing.pack_wino2d(wp2), device) if wino else None
         self.act1 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.01, scale=_dev(s1, device), shift=_dev(sh1, device),
                             post=POST_LRELU, post_slope=0.01)
         self.shortcut = None
@@ -271,8 +277,8 @@ class _ConvBlock:
             res = out
         else:
             res = x
-        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d)
-        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d)
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg=self.w1g)
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg=self.w2g)
 
 
 class RestorerEngine:
