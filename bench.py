@@ -307,7 +307,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 16: conv_x3_kernel,
-    # 70 / 79: convwg_kernel (Winograd F(2,3): 1-D / 3x3 on pitch maps),
+    # 70 / 79: convwg_kernel (Winograd F(2,3): 1-D / 3x3 on pitch maps), 71/72/74: fused layer with a Winograd second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
     import re
@@ -315,14 +315,17 @@ def main():
     def family(tile):
         bm, bl, code = tile // 100000, tile // 100 % 1000, tile % 100
         if code in (51, 52, 54):
-            return ("w1d", bm, bl), "convw_kernel<%d,%d,*,*,NT=2|3,*,false>" % (bm, bl), \
-                   r"convw_kernel<%d, %d, \d+, \d+, [23], \d+, false>" % (bm, bl)
+            return ("w1d", bm, bl), "convw_kernel<%d,%d,*,*,NT=2|3,*,0>" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, [23], \d+, 0>" % (bm, bl)
         if code == 59:
-            return ("w2d", bm, bl), "convw_kernel<%d,%d,*,*,NT=9,*,false>" % (bm, bl), \
-                   r"convw_kernel<%d, %d, \d+, \d+, 9, \d+, false>" % (bm, bl)
+            return ("w2d", bm, bl), "convw_kernel<%d,%d,*,*,NT=9,*,0>" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, 9, \d+, 0>" % (bm, bl)
         if code in (61, 62, 64):
-            return ("wfused", bm, bl), "convw_kernel<%d,%d,*,*,3,*,true> (fused ResStack layer)" % (bm, bl), \
-                   r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, true>" % (bm, bl)
+            return ("wfused", bm, bl), "convw_kernel<%d,%d,*,*,3,*,1> (fused ResStack layer)" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, 1>" % (bm, bl)
+        if code in (71, 72, 74):
+            return ("wfusedw", bm, bl), "convw_kernel<%d,%d,*,*,3,*,2> (fused ResStack layer, Winograd second half)" % (bm, bl), \
+                   r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, 2>" % (bm, bl)
         if code in (70, 79):
             wgm = bm // 32
             if code == 79:
@@ -339,6 +342,8 @@ def main():
     # forms 4 products per pair of outputs where the direct sum has 6.  `achieved` / `frac` below count executed MFMA
     # work (what the matrix pipe can be compared with); the direct-convolution equivalent is reported next to it.
     def exec_factor(key):
+        if key[0] == "wfusedw":
+            return 5.0 / 6.0   # the dilated half direct (3 products per output), the dilation-1 half Winograd (2)
         return 2.0 / 3.0 if key[0] in ("wino", "wino2d") else 1.0
 
     by_fam = {}

@@ -141,6 +141,12 @@ int vfx_conv1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias
 int vfx_resblock_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
                      const float* w2_direct, const float* bias2, int B, int C, int L, int dilation, float slope,
                      int post_act, float post_slope, vfx_stream_t stream);
+/* The same with the SECOND convolution's weights also given in the Winograd layout of vfx_act.w_wino (may be NULL): the
+ * dilation-1 half of the layer then forms 4 products per output pair instead of 6 on the LDS tile (C = 64 with the
+ * 256-column tile, C = 128).  Results differ from vfx_resblock_f32 by fp32 rounding only. */
+int vfx_resblock2_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
+                      const float* w2_direct, const float* bias2, const float* w2_wino, int B, int C, int L,
+                      int dilation, float slope, int post_act, float post_slope, vfx_stream_t stream);
 
 /* ConvTranspose1d(Cin, Cout, kernel 2s, stride s, padding s/2 + s%2, output_padding s%2):
  * Lin -> s*Lin.  Polyphase: s phases x 2 taps.  w_packed = [2s][CinPad][Cout], slab k is

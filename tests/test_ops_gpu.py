@@ -460,6 +460,16 @@ def test_resblock_fused(case):
         ops.resblock(xd, xd, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil)      # in place is refused
     with pytest.raises(_lib.VfxError):
         ops.resblock(xd[:, :32], yd[:, :32], w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil)   # C = 32 is not covered
+    # the same layer with its dilation-1 half as Winograd F(2,3) on the LDS tile (vfx_resblock2_f32, w2_wino)
+    yd2 = ops.guarded(B, Cn, L, 2187 + 264, DEV)
+    yd2._vfx_base.fill_(float("nan"))
+    ops.resblock(xd, yd2, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2,
+                 w2g=packing.pack_wino(packing.pack_conv1d(w2)).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (71, 72, 74)
+    _close(yd2[:, :, :L], ref, 2e-5)
+    base = yd2._vfx_base
+    assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()
 
 
 

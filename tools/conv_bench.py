@@ -99,7 +99,9 @@ def main():
             w1d = packing.pack_direct(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
             w2d = packing.pack_direct(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
             bias = torch.zeros(cout, device=dev)
-            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil)
+            w2g = (packing.pack_wino(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
+                   if args.wg else None)
+            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil, w2g=w2g)
             macs = 2 * B * L * cin * cout * 3
         elif kind == "t1":
             s = k

@@ -124,7 +124,7 @@ class VocoderEngine:
                 layers.append(_wpair(wa, device) + (_dev(sd[a + ".bias"], device),) +
                               _wpair(wb, device) + (_dev(sd[b + ".bias"], device),) +
                               ((_dev(packing.pack_wino(wa), device), _dev(packing.pack_wino(wb), device)) if wino
-                               else (None, None)))
+                               else (None, _dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C else None)))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -197,7 +197,7 @@ class VocoderEngine:
                     if last:
                         post, pslope = (POST_LRELU if j == nst - 1 else POST_LRELU_SNAKE), 0.2
                     src, dst = (xs, ys) if i % 2 == 0 else (ys, xs)
-                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope)
+                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=w2g)
                     continue
                 if not wino:
                     w1g = w2g = None
