@@ -1170,7 +1170,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
     std::lock_guard<std::mutex> lock(mu);
     auto& e = pool[std::make_pair(dev, s)];
     if (e.second < bytes) {
-        if (e.first) hipFree(e.first);  // (waits for the launches that still use it)
+        if (e.first) (void)hipFree(e.first);  // (waits for the launches that still use it)
         e.first = nullptr;
         e.second = 0;
         const size_t want = bytes + bytes / 2;
