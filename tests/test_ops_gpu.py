@@ -589,7 +589,9 @@ def test_conv2d_3x3_convw(cfg):
 
 @pytest.mark.parametrize("cfg", [(32, 64, 64, 128, 6, True, False), (32, 32, 64, 128, 6, False, True), (32, 128, 128, 64, 5, True, True),
                                  (32, 64, 128, 64, 5, False, True), (32, 384, 384, 128, 3, True, True),
-                                 (32, 256, 128, 130, 4, True, False), (48, 128, 64, 99, 5, True, True)])
+                                 (32, 256, 128, 130, 4, True, False), (48, 128, 64, 99, 5, True, True),
+                                 (32, 32, 32, 256, 7, True, True), (32, 64, 32, 64, 7, False, False),   # Cout = 32: 32 ch x 256 pairs
+                                 (32, 16, 32, 129, 6, True, False)])
 def test_conv2d_3x3_winograd(cfg):
     """3x3 on a pitch map on convwg_kernel<.., NKX = 3> (vfx_act.w_wino = packing.pack_wino2d): Winograd F(2,3) along
     the map rows, 12 products per output pair instead of 18.  Same contract as the direct kernels: eval-BatchNorm

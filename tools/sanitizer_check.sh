@@ -5,4 +5,4 @@
 export VFX_LIB=$PWD/voicefixer_amd/libvfx_hip_ubsan.so
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 python -m pytest tests/test_ops_gpu.py tests/test_api_gpu.py -q -m gpu -x \
-    -k "bad_arguments or test_conv1d or convtr or resblock or conv2d or stft_mel or frame_count or restore_inmem_matches_golden or hf_cut or gru" "$@"
+    -k "bad_arguments or test_conv1d or convtr or resblock or conv2d or stft_mel or ragged or restore_inmem_matches_golden or hf_cut or gru" "$@"

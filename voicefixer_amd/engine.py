@@ -107,7 +107,10 @@ class VocoderEngine:
         self.condnet = []
         for i in (0, 2, 4, 6, 8):
             p = "condnet.%d" % i
-            self.condnet.append(_wpair(packing.pack_conv1d(wn(p)), device) + (_dev(sd[p + ".bias"], device),))
+            wc = packing.pack_conv1d(wn(p))
+            wcg = (_dev(packing.pack_wino(wc), device)
+                   if WINO_MIN_C > 0 and wc.shape[1] % 32 == 0 and wc.shape[2] % 64 == 0 else None)
+            self.condnet.append(_wpair(wc, device) + (_dev(sd[p + ".bias"], device), wcg))
         self.pre = (_dev(packing.pack_conv1d(wn("generator.1")), device), _dev(sd["generator.1.bias"], device))
         self.stages = []
         for j, s in enumerate(weights.UPSAMPLE_SCALES):
@@ -161,9 +164,10 @@ class VocoderEngine:
         a = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev, rows(1))
         b = _rows(B, weights.COND_CHANNELS, Tc, G_TILE, dev, rows(1))
         x = cond
-        for i, (w, wd, bias) in enumerate(self.condnet):
+        for i, (w, wd, bias, wg) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
-            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w), wd=wd)
+            ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w), wd=wd,
+                       wg=wg if self.math == "f32" else None)
             x = y
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
@@ -246,9 +250,11 @@ class _ConvBlock:
         self.b1 = _dev(sh2, device)
         self.w2, self.w2d = _wpair(wp2, device)
         # Winograd F(2,3) along the map rows (convwg_kernel, NKX = 3) where the kernel has an instance
-        wino = WINO2D and self.cout % 64 == 0
-        self.w1g = _dev(packing.pack_wino2d(wp1), device) if wino and self.cin % 32 == 0 else None
-        self.w2g = _dev(packing.pack_wino2d(wp2), device) if wino else None
+        # (instances: Cout % 64 == 0 with Cin % 32 == 0; Cout = 32 with Cin % 16 == 0)
+        cin_step = 32 if self.cout % 64 == 0 else 16
+        wino = WINO2D and self.cout % 32 == 0
+        self.w1g = _dev(packing.pack_wino2d(wp1), device) if wino and self.cin % cin_step == 0 else None
+        self.w2g = _dev(packing.pack_wino2d(wp2), device) if wino and self.cout % cin_step == 0 else None
         self.act1 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.01, scale=_dev(s1, device), shift=_dev(sh1, device),
                             post=POST_LRELU, post_slope=0.01)
         self.shortcut = None
