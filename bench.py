@@ -307,7 +307,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 16: conv_x3_kernel,
-    # 70 / 79: convwg_kernel (Winograd F(2,3): 1-D / 3x3 on pitch maps), 71/72/74: fused layer with a Winograd second half,
+    # 70 / 79: convwg_kernel (Winograd F(2,3): 1-D / 3x3 on pitch maps), 80: convwg4_kernel (Winograd F(4,3)), 71/72/74: fused layer with a Winograd second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
     import re
@@ -326,6 +326,10 @@ def main():
         if code in (71, 72, 74):
             return ("wfusedw", bm, bl), "convw_kernel<%d,%d,*,*,3,*,2> (fused ResStack layer, Winograd second half)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, 2>" % (bm, bl)
+        if code == 80:
+            wgm = bm // 32
+            return ("wino4", bm, bl), "convwg4_kernel<%d,%d> (Winograd F(4,3), %d ch x %d output quads)" % (
+                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d>" % (wgm, 4 // wgm)
         if code in (70, 79):
             wgm = bm // 32
             if code == 79:
@@ -342,6 +346,8 @@ def main():
     # forms 4 products per pair of outputs where the direct sum has 6.  `achieved` / `frac` below count executed MFMA
     # work (what the matrix pipe can be compared with); the direct-convolution equivalent is reported next to it.
     def exec_factor(key):
+        if key[0] == "wino4":
+            return 0.5         # six products per four outputs; the direct sum has twelve
         if key[0] == "wfusedw":
             return 5.0 / 6.0   # the dilated half direct (3 products per output), the dilation-1 half Winograd (2)
         return 2.0 / 3.0 if key[0] in ("wino", "wino2d") else 1.0
@@ -396,8 +402,9 @@ def main():
                      for d in sorted(by_fam.values(), key=lambda d: -d[2])[:8]},
     }
     if xf != 1.0:
-        roofline["algorithm"] = ("Winograd F(2,3) along the dilated axis: 4 fp32 MFMA products per output pair instead "
-                                 "of 6; achieved / frac / algorithmic_gflop_per_launch count the EXECUTED products")
+        roofline["algorithm"] = ("Winograd %s along the dilated axis: %s; achieved / frac / algorithmic_gflop_per_launch "
+                                 "count the EXECUTED products" % (("F(4,3)", "6 fp32 MFMA products per 4 outputs instead of 12")
+                                                                if xf == 0.5 else ("F(2,3)", "4 fp32 MFMA products per output pair instead of 6")))
         roofline["direct_conv_gflop_per_launch"] = round(2.0 * macs / launches / 1e9, 3)
         roofline["direct_equivalent_tflops"] = round(2.0 * macs / secs / 1e12, 2)
 

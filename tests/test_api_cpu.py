@@ -225,3 +225,33 @@ def test_pack_wino_is_the_f23_weight_transform():
                 m[k] = m[k] + U2[kx * 4 + k].t() @ V[k]
         assert torch.allclose(m[0] + m[1] + m[2], ref2[:, h, xx], atol=1e-5)
         assert torch.allclose(m[1] - m[2] - m[3], ref2[:, h + 1, xx], atol=1e-5)
+
+
+def test_pack_wino4_is_the_f43_weight_transform():
+    """packing.pack_wino4 (vfx_act.w_wino4): with V = B^T d of the six inputs x[q-d] .. x[q+4d] and m_k = U_k V_k, A^T m
+    must be the direct k = 3 convolution at q, q+d, q+2d, q+3d -- float64 evaluation from the PACKED weights; and the
+    accumulator start values of convwg4_kernel (m2 = m4 = 0) must reproduce bias + residual on all four outputs."""
+    import torch.nn.functional as F
+    from voicefixer_amd import packing
+    g = torch.Generator().manual_seed(6)
+    cin, cout, L, d = 16, 32, 60, 3
+    w = torch.randn((cout, cin, 3), generator=g)
+    x = torch.randn((1, cin, L), generator=g)
+    ref = F.conv1d(x.double(), w.double(), dilation=d, padding=d)[0]
+    U = _unpack_direct(packing.pack_wino4(packing.pack_conv1d(w))).double()           # [6][Cin][Cout]
+    BT = torch.tensor([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0],
+                       [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]], dtype=torch.float64)
+    AT = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64)
+    xp = F.pad(x.double()[0], (d, 4 * d))
+    for q in (0, 2, 11, L - 3 * d - 1):
+        dd = torch.stack([xp[:, q + j * d] for j in range(6)])                        # x[q-d] .. x[q+4d], [6][Cin]
+        V = BT @ dd
+        m = torch.stack([U[k].t() @ V[k] for k in range(6)])                          # [6][Cout]
+        y = AT @ m
+        for i in range(4):
+            assert torch.allclose(y[i], ref[:, q + i * d], atol=1e-5)
+    t = torch.randn(4, dtype=torch.float64)
+    m3 = 0.5 * (t[2] - t[1])
+    m1 = 2 * t[1] - t[2]
+    start = torch.tensor([t[0] - m1 - m3, m1, 0, m3, 0, t[3] - m1 - 8 * m3])
+    assert torch.allclose(AT @ start, t, atol=1e-12)

@@ -334,6 +334,65 @@ def test_conv1d_winograd(case):
         assert torch.isnan(yd2[:, :, L:]).all()
 
 
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv1d_winograd4(case):
+    """convwg4_kernel (vfx_act.w_wino4): the k = 3 Conv1d as Winograd F(4,3) -- six fp32 MFMA products per FOUR outputs.
+    Same contract as test_conv1d_winograd; the transform constants (up to 8) cost about ten times the rounding error of
+    F(2,3), still inside the tolerance of the direct kernels."""
+    B, Cin, Cout, L, dil, pre, post, use_res = case
+    x = _rand((B, Cin, L), 261)
+    w = _rand((Cout, Cin, 3), 262, (Cin * 3) ** -0.5)
+    bias = _rand((Cout,), 263, 0.1)
+    res = _rand((B, Cout, L), 264) if use_res else None
+    ref = F.conv1d(_ref_act(x, pre, 0.01), w, bias, dilation=dil, padding=dil)
+    if use_res:
+        ref = ref + res
+    ref = _ref_post(ref, post, 0.2)
+    lp = (L + 67) // 4 * 4
+    xd = torch.full((B, Cin, lp), float("nan"), device=DEV)     # no guard band; NaN right after the row
+    xd[:, :, :L] = x.to(DEV)
+    yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+    rd = _padded(res, lp) if use_res else None
+    act = ops.Act(pre=pre, pre_slope=0.01, post=post, post_slope=0.2)
+    wp = packing.pack_conv1d(w)
+    wg4 = packing.pack_wino4(wp).to(DEV)
+    before = _lib.lib().vfx_launch_count()
+    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, rd, wg4=wg4)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 80, "launch did not run on convwg4_kernel"
+    _close(yd[:, :, :L], ref, 2e-5)
+    assert torch.isnan(yd[:, :, L:]).all()
+    if use_res and post == _lib.POST_NONE:
+        rd2 = _padded(res, lp)   # in-place residual update
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), rd2, L, 3, dil, 0, act, rd2, wg4=wg4)
+        torch.cuda.synchronize()
+        _close(rd2[:, :, :L], ref, 2e-5)
+
+
+def test_conv1d_winograd4_ragged_rows():
+    """Per-row lengths through the quad kernel: every row equals the same row convolved alone."""
+    B, C, L = 8, 256, 4100
+    lens = [4100, 4099, 2050, 2051, 3000, 54, 4047, 1]
+    x = _rand((B, C, L), 271)
+    w = _rand((C, C, 3), 272, (C * 3) ** -0.5)
+    bias = _rand((C,), 273, 0.1)
+    wp = packing.pack_conv1d(w)
+    wg4 = packing.pack_wino4(wp).to(DEV)
+    act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01)
+    for dil in (27, 1, 729):
+        xd = _guarded_nan(x, 8)
+        yd = torch.full((B, C, L + 60), float("nan"), device=DEV)
+        ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
+        torch.cuda.synchronize()
+        assert _lib.lib().vfx_last_conv_tile() % 100 == 80
+        for r, n in enumerate(lens):
+            ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
+            _close(yd[r:r + 1, :, :n], ref, 2e-5)
+            assert torch.isnan(yd[r, :, n:]).all()
+
+
 def test_conv1d_winograd_ragged_rows_and_fallback():
     """Per-row lengths: every row of a ragged launch equals the same row convolved alone (zero padding at ITS end);
     small launches and shapes the kernel does not cover fall back to the direct kernels with the same result."""

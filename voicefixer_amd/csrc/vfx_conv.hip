@@ -1387,6 +1387,10 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         const int rc3 = try_launch_x3(a, x, nphase, phs, act->w_x3, stream);
         if (rc3 != VFX_ENOTSUP) return rc3;
     }
+    if (act && act->w_wino4) {
+        const int rc4 = try_launch_convwg4(a, x, nphase, phs, act->w_wino4, stream);
+        if (rc4 != VFX_ENOTSUP) return rc4;
+    }
     if (act && act->w_wino) {
         int rcg = VFX_ENOTSUP;
         if (nphase == 1 && phs[0].ntaps == 9 && in_mask > 0) {

@@ -88,6 +88,9 @@ FUSE_MAX_C = 128  # ResStack stages with at most this many channels can run one 
 # second launch reads the intermediate AND the residual from HBM: 10.9 GB, bandwidth-bound) -- so the C = 64 stage
 # keeps the fused layer.  VFX_WINO_MIN_C=64 / 0: development switch.
 WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
+# ... and, from this channel count on, on the F(4,3) kernel (convwg4_kernel: 2x fewer MFMAs than the direct sum; measured per
+# convolution at batch 32: C = 256 3.69 -> 3.09 ms, C = 512 2.18 -> 1.85 ms, C = 128 no gain: 8 chunks per tile are too few)
+WINO4_MIN_C = int(_os.environ.get("VFX_WINO4_MIN_C", "256"))
 WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"   # the same for the 3x3 convolutions of the ResUNet (Cout % 64 == 0)
 
 
@@ -124,10 +127,13 @@ class VocoderEngine:
                 a = "%s.layers.%d.1" % (rs, i)
                 b = "%s.layers.%d.3" % (rs, i)
                 wa, wb = packing.pack_conv1d(wn(a)), packing.pack_conv1d(wn(b))
+                wino4 = wino and WINO4_MIN_C > 0 and cst >= WINO4_MIN_C
                 layers.append(_wpair(wa, device) + (_dev(sd[a + ".bias"], device),) +
                               _wpair(wb, device) + (_dev(sd[b + ".bias"], device),) +
                               ((_dev(packing.pack_wino(wa), device), _dev(packing.pack_wino(wb), device)) if wino
-                               else (None, _dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C else None)))
+                               else (None, _dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C else None)) +
+                              ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if wino4
+                               else (None, None)))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -192,7 +198,7 @@ class VocoderEngine:
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
-            for i, (w1, w1d, b1, w2, w2d, b2, w1g, w2g) in enumerate(layers):
+            for i, (w1, w1d, b1, w2, w2d, b2, w1g, w2g, w1g4, w2g4) in enumerate(layers):
                 last = i == len(layers) - 1
                 if fused:
                     # one launch per layer, intermediate tile in LDS; input and output ping-pong between xs and ys
@@ -204,10 +210,11 @@ class VocoderEngine:
                     ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=w2g)
                     continue
                 if not wino:
-                    w1g = w2g = None
-                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg=w1g)
+                    w1g = w2g = w1g4 = w2g4 = None
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg=w1g, wg4=w1g4)
                 act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
-                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg=w2g)  # residual updated in place
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg=w2g,
+                           wg4=w2g4)  # residual updated in place
             assert len(layers) % 2 == 0  # the fused ping-pong ends in xs
             h = xs
             L = Lo

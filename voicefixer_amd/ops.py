@@ -103,7 +103,7 @@ _NOACT = None
 _ACTVARIANTS = {}
 
 
-def _act(a, w3=None, wd=None, wg=None):
+def _act(a, w3=None, wd=None, wg=None, wg4=None):
     """vfx_act* for a launch.  ``w3`` (packing.pack_x3 planes on the device) opts the launch into VFX_MATH_BF16X3 (the
     library falls back to fp32 for geometries its bf16x3 kernel does not cover); ``wd`` (packing.pack_direct on the
     device) offers the fp32 launch the convw_kernel weight layout (vfx_act.w_direct; the library decides); ``wg``
@@ -113,21 +113,22 @@ def _act(a, w3=None, wd=None, wg=None):
         if _NOACT is None:
             _NOACT = Act()
         a = _NOACT
-    if w3 is None and wd is None and wg is None:
+    if w3 is None and wd is None and wg is None and wg4 is None:
         return C.byref(a.c)
     key = (id(a), w3.data_ptr() if w3 is not None else 0, wd.data_ptr() if wd is not None else 0,
-           wg.data_ptr() if wg is not None else 0)
+           wg.data_ptr() if wg is not None else 0, wg4.data_ptr() if wg4 is not None else 0)
     ent = _ACTVARIANTS.get(key)
     if ent is None:
         c = vfx_act(a.c.pre_act, a.c.pre_slope, a.c.pre_scale, a.c.pre_shift, a.c.post_act, a.c.post_slope,
                     MATH_BF16X3 if w3 is not None else MATH_F32, w3.data_ptr() if w3 is not None else None,
-                    wd.data_ptr() if wd is not None else None, wg.data_ptr() if wg is not None else None)
-        ent = _ACTVARIANTS[key] = (c, a, w3, wd, wg)  # keep the owners alive with the struct
+                    wd.data_ptr() if wd is not None else None, wg.data_ptr() if wg is not None else None,
+                    wg4.data_ptr() if wg4 is not None else None)
+        ent = _ACTVARIANTS[key] = (c, a, w3, wd, wg, wg4)  # keep the owners alive with the struct
     return C.byref(ent[0])
 
 
 def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None, wd=None,
-           wg=None):
+           wg=None, wg4=None):
     """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout]."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
@@ -137,7 +138,7 @@ def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=Non
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3, wd, wg), _stream())
+                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3, wd, wg, wg4), _stream())
     check(rc, "vfx_conv1d_f32")
     _prof_end(e0, B * L * cin * cout * k)
 

@@ -62,6 +62,17 @@ def pack_wino(w_packed):
     return pack_direct(u.float())
 
 
+def pack_wino4(w_packed):
+    """[3][CinPad][Cout] -> [6][CinPad/8][Cout][8]: the Winograd F(4,3) weight transform U = G w,
+    G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]] (float64, rounded once),
+    in the A-operand layout of pack_direct, for convwg4_kernel (vfx_act.w_wino4)."""
+    assert w_packed.shape[0] == 3
+    g0, g1, g2 = w_packed.double()
+    u = torch.stack([g0 / 4, -(g0 + g1 + g2) / 6, -(g0 - g1 + g2) / 6, g0 / 24 + g1 / 12 + g2 / 6,
+                     g0 / 24 - g1 / 12 + g2 / 6, g2])
+    return pack_direct(u.float())
+
+
 def pack_wino2d(w_packed):
     """[9][CinPad][Cout] (3x3 slabs ky*3 + kx) -> [12][CinPad/8][Cout][8], slab kx*4 + plane: the Winograd F(2,3) weight
     transform along the kernel's ROW axis ky for every kernel column kx (convwg_kernel with NKX = 3, vfx_act.w_wino of
