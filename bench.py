@@ -326,10 +326,13 @@ def main():
         if code in (71, 72, 74):
             return ("wfusedw", bm, bl), "convw_kernel<%d,%d,*,*,3,*,2> (fused ResStack layer, Winograd second half)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, 2>" % (bm, bl)
-        if code == 80:
+        if code in (80, 89):
             wgm = bm // 32
-            return ("wino4", bm, bl), "convwg4_kernel<%d,%d> (Winograd F(4,3), %d ch x %d output quads)" % (
-                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d>" % (wgm, 4 // wgm)
+            if code == 89:
+                return ("wino4", bm, bl, 3), "convwg4_kernel<%d,%d,3> (3x3 as Winograd F(4,3) along the map rows)" % (
+                    wgm, 4 // wgm), r"convwg4_kernel<%d, %d, 3>" % (wgm, 4 // wgm)
+            return ("wino4", bm, bl), "convwg4_kernel<%d,%d,1> (Winograd F(4,3), %d ch x %d output quads)" % (
+                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, 1>" % (wgm, 4 // wgm)
         if code in (70, 79):
             wgm = bm // 32
             if code == 79:

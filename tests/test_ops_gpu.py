@@ -694,6 +694,51 @@ def test_conv2d_3x3_winograd(cfg):
         _close(_from_pitch(rd2, H, lp)[..., : P - 1], ref, 2e-5)
 
 
+@pytest.mark.parametrize("cfg", [(32, 64, 64, 128, 6, True, False), (32, 32, 64, 128, 6, False, True), (32, 128, 128, 64, 5, True, True),
+                                 (32, 384, 384, 128, 3, True, True), (32, 256, 128, 130, 4, True, False),
+                                 (48, 128, 64, 99, 5, True, True)])
+def test_conv2d_3x3_winograd4(cfg):
+    """3x3 on a pitch map on convwg4_kernel<.., NKX = 3> (vfx_act.w_wino4 = packing.pack_wino4_2d): Winograd F(4,3) along
+    the map rows, 18 products per four outputs instead of 36; same contract as test_conv2d_3x3_winograd (map heights that
+    are not multiples of 4 included)."""
+    B, Cin, Cout, H, lp, affine, use_res = cfg
+    P = 1 << lp
+    x = _rand((B, Cin, H, P - 1), 311)
+    w = _rand((Cout, Cin, 3, 3), 312, (Cin * 9) ** -0.5)
+    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(313))
+    shift = _rand((Cin,), 314, 0.3)
+    bias = _rand((Cout,), 316, 0.1)
+    res = _rand((B, Cout, H, P - 1), 315) if use_res else None
+    xin = _ref_act(x, _lib.PRE_AFFINE_LRELU, 0.01, scale, shift) if affine else x
+    ref = F.conv2d(xin, w, bias, padding=1)
+    if use_res:
+        ref = ref + res
+    ref = F.leaky_relu(ref, 0.01) if affine else ref
+    G = P + 1 + 264
+    xd = ops.guarded(B, Cin, H * P, G, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xd[:, :, :H * P] = _to_pitch(x, lp).to(DEV)
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    rd = torch.nan_to_num(_to_pitch(res, lp).to(DEV), nan=0.0) if use_res else None
+    act = (ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=scale.to(DEV), shift=shift.to(DEV),
+                   post=_lib.POST_LRELU, post_slope=0.01) if affine else None)
+    wp = packing.pack_conv2d(w)
+    wg4 = packing.pack_wino4_2d(wp).to(DEV)
+    before = _lib.lib().vfx_launch_count()
+    ops.conv2d(xd, wp.to(DEV), bias.to(DEV), yd, H, lp, 3, act, rd, wg4=wg4)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_launch_count() == before + 1
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 89, "launch did not run on convwg4_kernel (3x3)"
+    got = _from_pitch(yd, H, lp)
+    _close(got[..., : P - 1], ref, 2e-5)
+    assert (got[..., P - 1] == 0).all()  # pad column written as zero
+    if use_res:
+        rd2 = rd.clone()
+        ops.conv2d(xd, wp.to(DEV), bias.to(DEV), rd2, H, lp, 3, act, rd2, wg4=wg4)
+        torch.cuda.synchronize()
+        _close(_from_pitch(rd2, H, lp)[..., : P - 1], ref, 2e-5)
+
+
 @pytest.mark.parametrize("cfg", [(2, 32, 32, 64, 7, True, True), (1, 64, 64, 48, 6, True, False),
                                  (2, 128, 128, 16, 5, False, True), (1, 384, 384, 8, 3, True, True),
                                  (1, 768, 384, 8, 3, False, False), (1, 64, 128, 32, 5, True, False)])

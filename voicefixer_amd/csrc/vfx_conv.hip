@@ -1388,7 +1388,15 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         if (rc3 != VFX_ENOTSUP) return rc3;
     }
     if (act && act->w_wino4) {
-        const int rc4 = try_launch_convwg4(a, x, nphase, phs, act->w_wino4, stream);
+        int rc4 = VFX_ENOTSUP;
+        if (nphase == 1 && phs[0].ntaps == 9 && in_mask > 0) {
+            const int P = in_mask + 1;
+            bool ok = true;
+            for (int t = 0; t < 9; ++t) ok &= phs[0].taps[t].off == (t / 3 - 1) * P + (t % 3 - 1) && phs[0].taps[t].slab == t;
+            if (ok) rc4 = try_launch_convwg4_2d(a, x, P, act->w_wino4, stream);
+        } else {
+            rc4 = try_launch_convwg4(a, x, nphase, phs, act->w_wino4, stream);
+        }
         if (rc4 != VFX_ENOTSUP) return rc4;
     }
     if (act && act->w_wino) {

@@ -91,7 +91,8 @@ WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 # ... and, from this channel count on, on the F(4,3) kernel (convwg4_kernel: 2x fewer MFMAs than the direct sum; measured per
 # convolution at batch 32: C = 256 3.69 -> 3.09 ms, C = 512 2.18 -> 1.85 ms, C = 128 no gain: 8 chunks per tile are too few)
 WINO4_MIN_C = int(_os.environ.get("VFX_WINO4_MIN_C", "256"))
-WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"   # the same for the 3x3 convolutions of the ResUNet (Cout % 64 == 0)
+WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"
+WINO4_2D = _os.environ.get("VFX_WINO4_2D", "1") != "0"   # F(4,3) for the 3x3 convolutions with Cout % 64 == 0   # the same for the 3x3 convolutions of the ResUNet (Cout % 64 == 0)
 
 
 class VocoderEngine:
@@ -262,6 +263,10 @@ class _ConvBlock:
         wino = WINO2D and self.cout % 32 == 0
         self.w1g = _dev(packing.pack_wino2d(wp1), device) if wino and self.cin % cin_step == 0 else None
         self.w2g = _dev(packing.pack_wino2d(wp2), device) if wino and self.cout % cin_step == 0 else None
+        # ... and F(4,3) (convwg4_kernel, NKX = 3) for the wide instances
+        wino4 = WINO2D and WINO4_2D and self.cout % 64 == 0
+        self.w1g4 = _dev(packing.pack_wino4_2d(wp1), device) if wino4 and self.cin % 32 == 0 else None
+        self.w2g4 = _dev(packing.pack_wino4_2d(wp2), device) if wino4 else None
         self.act1 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.01, scale=_dev(s1, device), shift=_dev(sh1, device),
                             post=POST_LRELU, post_slope=0.01)
         self.shortcut = None
@@ -290,8 +295,9 @@ class _ConvBlock:
             res = out
         else:
             res = x
-        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg=self.w1g)
-        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg=self.w2g)
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg=self.w1g,
+                   wg4=self.w1g4)
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg=self.w2g, wg4=self.w2g4)
 
 
 class RestorerEngine:

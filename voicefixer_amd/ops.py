@@ -168,7 +168,7 @@ def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None, wd=None):
     _prof_end(e0, B * Lin * cin * cout * 2 * stride)
 
 
-def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3=None, wd=None, wg=None):
+def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3=None, wd=None, wg=None, wg4=None):
     """x (B,Cin,H*P) pitch map -> y (B,Cout,H*P)."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
@@ -178,7 +178,7 @@ def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv2d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act, w3, wd, wg), _stream())
+                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act, w3, wd, wg, wg4), _stream())
     check(rc, "vfx_conv2d_f32")
     _prof_end(e0, B * H * ((1 << pitch_log2) - 1) * cin * cout * ksize * ksize)
 

@@ -73,6 +73,22 @@ def pack_wino4(w_packed):
     return pack_direct(u.float())
 
 
+def _f43(g0, g1, g2):
+    return [g0 / 4, -(g0 + g1 + g2) / 6, -(g0 - g1 + g2) / 6, g0 / 24 + g1 / 12 + g2 / 6, g0 / 24 - g1 / 12 + g2 / 6, g2]
+
+
+def pack_wino4_2d(w_packed):
+    """[9][CinPad][Cout] (3x3 slabs ky*3 + kx) -> [18][CinPad/8][Cout][8], slab kx*6 + plane: the Winograd F(4,3) weight
+    transform along the kernel's ROW axis for every kernel column (convwg4_kernel with NKX = 3, vfx_act.w_wino4 of
+    vfx_conv2d_f32)."""
+    assert w_packed.shape[0] == 9
+    g = w_packed.double().reshape(3, 3, w_packed.shape[1], w_packed.shape[2])   # [ky][kx]
+    planes = []
+    for kx in range(3):
+        planes += _f43(g[0, kx], g[1, kx], g[2, kx])
+    return pack_direct(torch.stack(planes).float())
+
+
 def pack_wino2d(w_packed):
     """[9][CinPad][Cout] (3x3 slabs ky*3 + kx) -> [12][CinPad/8][Cout][8], slab kx*4 + plane: the Winograd F(2,3) weight
     transform along the kernel's ROW axis ky for every kernel column kx (convwg_kernel with NKX = 3, vfx_act.w_wino of
