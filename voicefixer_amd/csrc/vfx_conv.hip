@@ -1056,13 +1056,15 @@ static inline int floor4(int v) { return v >= 0 ? (v & ~3) : -(((-v) + 3) & ~3);
 
 template <int BM, int BL, int WGM, int WGL, int KC, bool FAST, int NXV = 4, bool SPLITK = false>
 static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0;   // bit d: the attribute is set on device d (one process may drive several)
+    int attr_dev = 0;
+    if (hipGetDevice(&attr_dev) != hipSuccess) attr_dev = 0;
     auto kern = conv_taps_kernel<BM, BL, WGM, WGL, KC, FAST, NXV, SPLITK>;
-    if (!attr_set) {
+    if (!((attr_set >> (attr_dev & 63)) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set |= 1ull << (attr_dev & 63);
     }
     {
         static const bool dump = getenv("VFX_DEBUG_ARGS") && atoi(getenv("VFX_DEBUG_ARGS")) != 0;  // development
@@ -1190,13 +1192,15 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 
 template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS = 1>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0;   // bit d: the attribute is set on device d (one process may drive several)
+    int attr_dev = 0;
+    if (hipGetDevice(&attr_dev) != hipSuccess) attr_dev = 0;
     auto kern = conv_x3_kernel<BM, BL, WGM, WGL, NT, MODE, ROWS>;
-    if (!attr_set) {
+    if (!((attr_set >> (attr_dev & 63)) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set |= 1ull << (attr_dev & 63);
     }
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     VFX_LAUNCHED();

@@ -186,13 +186,15 @@ extern "C" int vfx_gru_bidir_f32(const float* gi, const float* whh_packed, const
     if (!gi || !whh_packed || !bhh || !out || !out->ptr || B <= 0 || T <= 0 || B > 65535) return VFX_EINVAL;
     if (out->lstride != 1) return VFX_EALIGN;
     if (!vfx_aligned16(whh_packed)) return VFX_EALIGN;
-    static bool attr_set = false;
+    static unsigned long long attr_set = 0;   // bit d: the attribute is set on device d (one process may drive several)
+    int attr_dev = 0;
+    if (hipGetDevice(&attr_dev) != hipSuccess) attr_dev = 0;
     const size_t lds = (GRU_L_FLOATS + 2 * GRU_H + 3 * GRU_H) * sizeof(float);
-    if (!attr_set) {
+    if (!((attr_set >> (attr_dev & 63)) & 1ull)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gru_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set |= 1ull << (attr_dev & 63);
     }
     hipLaunchKernelGGL(gru_kernel, dim3(B, 2), dim3(512), lds, (hipStream_t)stream, gi, whh_packed, bhh,
                        (float*)out->ptr, out->bstride, out->cstride, T, (const int*)out->rows);
