@@ -255,3 +255,42 @@ def test_pack_wino4_is_the_f43_weight_transform():
     m1 = 2 * t[1] - t[2]
     start = torch.tensor([t[0] - m1 - m3, m1, 0, m3, 0, t[3] - m1 - 8 * m3])
     assert torch.allclose(AT @ start, t, atol=1e-12)
+
+
+def test_ragged_rows_length_vectors():
+    """engine.RaggedRows: the per-utterance lengths of every stage follow the reference's own shape rules
+    (SURVEY.md section 8: T = 1 + n // 441 frames, the UNet pads T to a multiple of 64 and halves it per level, the vocoder
+    appends T % 2 + 4 frames and upsamples by 7, 7, 3, 3)."""
+    from voicefixer_amd.engine import RaggedRows
+    lens = [1025, 44100, 441 * 64 - 1, 441 * 64, 441000, 1323000]
+    rg = RaggedRows(lens, "cpu")
+    assert rg.B == len(lens) and rg.n_max == 1323000 and rg.T_max == 3001
+    for b, n in enumerate(lens):
+        T = 1 + n // 441
+        Tp = -(-T // 64) * 64
+        Tc = T + T % 2 + 4
+        assert int(rg.n[b]) == n and int(rg.T[b]) == T
+        for k in range(7):
+            assert int(rg.unet[k][b]) == (Tp >> k) * (128 >> k)       # rows x pitch of a level-k map
+        for mult in (1, 7, 49, 147, 441):
+            assert int(rg.voc[mult][b]) == Tc * mult
+    assert int(rg.voc[441][4]) == 443646                             # the 10 s utterance of SURVEY.md section 8
+    assert rg.T.dtype == torch.int32
+
+
+def test_winograd_index_spaces_cover_every_position_once():
+    """The pair / quad index spaces of convwg_kernel / convwg4_kernel (vfx_convwg.inc: position q = 2d*blk + r resp.
+    4d*blk + i*d + r): restated here and checked to cover every output position of a row exactly once, for the dilations
+    of the ResStacks and the pitches of the UNet, with the block counts the launchers use."""
+    for L in (1, 2, 7, 54, 4099, 7042):
+        for d in (1, 3, 27, 128, 729, 2187):
+            for nout in (2, 4):
+                nblk = -(-L // (nout * d))
+                seen = [0] * L
+                for P in range(nblk * d):
+                    blk, r = divmod(P, d)
+                    q = nout * d * blk + r
+                    for i in range(nout):
+                        if q + i * d < L:
+                            seen[q + i * d] += 1
+                assert min(seen) == 1 and max(seen) == 1, (L, d, nout)
