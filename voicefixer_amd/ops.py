@@ -129,7 +129,9 @@ def _act(a, w3=None, wd=None, wg=None, wg4=None):
 
 def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None, wd=None,
            wg=None, wg4=None):
-    """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout]."""
+    """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout].  Optional weight layouts the library may use
+    instead (it decides per launch, see include/vfx_hip.h: vfx_act): w3 = bf16x3 planes (opts the launch into that
+    arithmetic), wd = packing.pack_direct, wg / wg4 = the Winograd F(2,3) / F(4,3) transforms (k = 3 only)."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
     cin = x.shape[1] if cin is None else cin
