@@ -100,7 +100,7 @@ typedef struct {
                                kx*4 + plane (packing.py::pack_wino2d); Cout % 64 == 0, Cin % 32 == 0, a guard band. */
     const float* w_wino4;   /* optional (may be NULL), k = 3 stride-1 Conv1d only: the Winograd F(4,3) transform, six
                                slabs U = G w (packing.py::pack_wino4): four outputs a dilation apart share six products
-                               (2x fewer fp32 MFMAs than the direct sum; rounding error ~10x that of w_wino, ~1e-6
+                               (2x fewer fp32 MFMAs than the direct sum; rounding error ~3x that of the direct sum, ~1e-6
                                relative).  Tried before w_wino; same shape conditions. */
 } vfx_act;
 

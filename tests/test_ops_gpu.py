@@ -337,8 +337,8 @@ def test_conv1d_winograd(case):
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv1d_winograd4(case):
     """convwg4_kernel (vfx_act.w_wino4): the k = 3 Conv1d as Winograd F(4,3) -- six fp32 MFMA products per FOUR outputs.
-    Same contract as test_conv1d_winograd; the transform constants (up to 8) cost about ten times the rounding error of
-    F(2,3), still inside the tolerance of the direct kernels."""
+    Same contract as test_conv1d_winograd; the transform constants (up to 8) cost about three times the rounding error
+    of the direct sum (tools/winograd_error.py), still inside the tolerance of the direct kernels."""
     B, Cin, Cout, L, dil, pre, post, use_res = case
     x = _rand((B, Cin, L), 261)
     w = _rand((Cout, Cin, 3), 262, (Cin * 3) ** -0.5)
