@@ -429,6 +429,10 @@ def main():
                                "utterances per step, VoiceFixer.restore mode 0, seeded random weights"
                                % (args.batch, args.seconds),
                    "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "frames": 1 + n // 441,
+                   "arithmetic": ("fp32 operands, fp32 MFMA accumulation everywhere; k=3 / 3x3 convolutions evaluated as Winograd "
+                                  "F(4,3) / F(2,3) (DESIGN.md 3.0b: half / two thirds of the direct sum's products, rounding "
+                                  "~3x / ~1.2x the direct sum's; VFX_WINO=0 runs the direct sums)") if args.math == "f32"
+                                 else "opt-in split-bf16 products (three bf16 MFMAs per fp32 product), fp32 accumulation",
                    "parallelism": "utterance sharding x%d (no data-path collective)" % world},
         "path_tflops": round(2.0 * path_macs(n) * args.batch * world * args.steps / dt / 1e12, 2),
         "roofline": roofline,
