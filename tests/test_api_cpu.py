@@ -294,3 +294,18 @@ def test_winograd_index_spaces_cover_every_position_once():
                         if q + i * d < L:
                             seen[q + i * d] += 1
                 assert min(seen) == 1 and max(seen) == 1, (L, d, nout)
+
+
+def test_model_attribute_is_a_module_handle():
+    """``VoiceFixer._model`` (base.py:13): reference callers move it between devices and look at its parameters
+    (test/streamlit.py:40-42) and reach the vocoder through it (base.py:127).  Here it is a handle: ``.to()`` / ``.eval()``
+    work, ``.train()`` is the unsupported mode 2, the weights stay in the engine."""
+    from voicefixer_amd import VoiceFixer, weights
+    vf = VoiceFixer.from_state(weights.seeded_vocoder_state(1), weights.seeded_restorer_state(2))
+    assert isinstance(vf._model, torch.nn.Module) and not vf._model.training
+    assert list(vf._model.parameters())[0].is_cuda is False
+    vf._model = vf._model.to("cpu")
+    assert vf._model.eval() is vf._model and vf._model.vocoder is vf._vocoder
+    with pytest.raises(NotImplementedError):
+        vf._model.train()
+    assert vf.eval() is vf                      # nn.Module.eval() on the owner reaches the handle with mode=False

@@ -511,3 +511,21 @@ def test_ragged_rows_at_folder_sizes(vf):
         e = _rms(out[r, :n].cpu().numpy(), alone.cpu().numpy())
         assert e < 2e-5, (r, n, e)
     pipe.check()
+
+
+def test_model_handle_forward_is_the_restorer(vf):
+    """``vf._model(sp, mel)`` (restorer/model.py:102-120): log-mel of the restored spectrogram, [B, 1, T, 128], equal to what
+    the pipeline computes between the STFT and the vocoder; ``sp`` is ignored as in the reference."""
+    g = torch.Generator().manual_seed(5)
+    wav = (0.1 * torch.randn(2, 22050, generator=g)).cuda()
+    pipe = vf._get_pipe()
+    mel, T = pipe.wav_to_mel(wav, 22050)
+    logmel, den = pipe.restorer.forward(mel, T)
+    out = vf._model(None, mel[:, None].cpu())
+    assert set(out) >= {"mel", "clean", "noisy", "unet_out"} and out["mel"].shape == (2, 1, T, 128)
+    assert not out["mel"].is_cuda                                       # follows the handle's placeholder device
+    assert torch.equal(out["mel"][:, 0], logmel.cpu())
+    assert torch.allclose(10 ** torch.clamp(out["mel"][:, 0], max=5), den.cpu(), rtol=1e-5)   # from_log (pytorch_util.py:24-27)
+    vf._model.to("cuda")
+    assert vf._model(None, mel[:, None])["mel"].is_cuda
+    vf._model.to("cpu")

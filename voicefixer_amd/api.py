@@ -168,6 +168,45 @@ class Vocoder(nn.Module):
         audio_io.save_wave((wav_re[:, 0, :L] * 2 ** 15).cpu().numpy(), out_path, sample_rate=self.rate)
 
 
+class _RestorerHandle(nn.Module):
+    """What reference callers reach through ``VoiceFixer._model`` (voicefixer/base.py:13,109; test/streamlit.py:40-42 does
+    ``list(vf._model.parameters())[0].is_cuda`` and ``vf._model = vf._model.to(device)``): an ``nn.Module`` with a
+    ``vocoder`` attribute whose call is the restorer's forward ``(sp, mel_noisy) -> {"mel": log-mel, ...}``
+    (restorer/model.py:102-120, 395-405).  The weights live in the engine's packed HIP buffers, so ``.to()`` only moves
+    the one placeholder parameter that makes ``parameters()`` non-empty; compute always runs on the MI355X."""
+
+    def __init__(self, owner):
+        super().__init__()
+        object.__setattr__(self, "_owner", owner)   # (not a sub-module: no cycle in nn.Module's registry)
+        self.placeholder = nn.Parameter(torch.zeros(1), requires_grad=False)
+        super().train(False)                        # base.py:30: the reference puts the restorer in eval mode at load time
+
+    @property
+    def vocoder(self):
+        return self._owner._vocoder
+
+    def train(self, mode=True):
+        if mode:
+            raise NotImplementedError("mode 2 (BatchNorm in train mode, base.py:115) is nondeterministic and not built")
+        return super().train(False)
+
+    @torch.no_grad()
+    def forward(self, sp, mel_orig):
+        """mel_orig: [B, 1, T, 128] linear mel -> {"mel": log10 of the restored mel [B, 1, T, 128], "clean", "noisy"};
+        ``sp`` is ignored exactly as in the reference (restorer/model.py:102: the argument is unused)."""
+        assert mel_orig.size()[-1] == 128
+        pipe = self._owner._get_pipe()
+        m = mel_orig.detach().to(pipe.device, torch.float32)[:, 0].contiguous()
+        dbg = {}
+        logmel, _ = pipe.restorer.forward(m, m.shape[1], debug=dbg)
+        pipe.check()
+        out = {"mel": logmel[:, None], "noisy": mel_orig,
+               "clean": (dbg["mask"].transpose(1, 2) * m)[:, None]}
+        out["unet_out"] = out["lstm_out"] = dbg["unet_out"][:, None]
+        dev = self.placeholder.device
+        return {k: (v if v.device == dev else v.to(dev)) for k, v in out.items()}
+
+
 class VoiceFixer(nn.Module):
     """General speech restoration, inference path (voicefixer/base.py)."""
 
@@ -192,6 +231,7 @@ class VoiceFixer(nn.Module):
         self._vocoder = vocoder
         self._restorer_state = restorer_state
         self._pipe = None
+        self._model = _RestorerHandle(self)   # the reference's attribute name (base.py:13); see _RestorerHandle
         self.math = "f32"       # "bf16x3": opt-in fast contraction arithmetic (set_math)
         self.segment_batch = 8  # 30 s segments of one long input restored per launch (~1.3 GB of HBM each)
 
