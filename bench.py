@@ -4,6 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 32] [--seconds 10]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Launched PLAIN with ``--gpus N`` (N > 1, no WORLD_SIZE in the environment) the script starts the ranks itself: it
+re-executes under ``torch.distributed.run --nnodes=1 --nproc-per-node min(N, visible devices)`` on 127.0.0.1 (one
+process per GPU, RCCL), says so loudly on stderr when fewer than N devices are visible, and the JSON line carries
+``n_gpus`` = ranks that really ran, ``requested_gpus``, ``visible_devices``, ``rccl`` and the device of every rank.
+
 One "step" = one pass of the hot path (STFT->mel -> denoiser+ResUNet -> vocoder -> peak/trim)
 over one batch of ``--batch`` synthetic ``--seconds``-second 44.1 kHz utterances already resident
 in HBM (BASELINE configs[2]: batched folder restore, batch 32 x 10 s, mode 0); consecutive steps
@@ -13,7 +18,9 @@ batches (utterances shard embarrassingly; no data-path collective): weak scaling
 
 ``host_to_host`` (same JSON line) is the metric as SURVEY.md 8(d) defines it: pinned host waveforms in,
 pinned host waveforms out, H2D of batch k+1 and D2H of batch k-1 on copy streams overlapping the compute of
-batch k (double buffered), everything inside the timed region.  It is never ``value``.
+batch k (double buffered), everything inside the timed region.  The bench contract defines ``value`` with the inputs
+already resident in HBM ("the PCIe-inclusive rate ... is never value"); the host-to-host figure therefore sits beside
+it as ``value_host_to_host`` (the two differ by < 1 %: the copies hide behind the compute).
 
 ``--scatter`` (BASELINE configs[3], launched under torch.distributed.run): rank 0 owns 256 x N utterances,
 ``dist.restore_sharded`` scatters them over RCCL (backend "nccl"), every rank restores its 256 in batches of
@@ -41,6 +48,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (no 2:1 sparsity), same guide
 SR = 44100
+TRAFFIC_PROFILE = "r03_pmc_hbm_traffic_bench_b32.json"  # tools/profile_round.sh -> tools/pmc_summary.py
 
 
 def synth_batch(batch, n, seed, device):
@@ -79,28 +87,50 @@ def cpu_model():
 
 def cpu_baseline(args, w1, gpu_out):
     """The CPU oracle (a port of the reference path onto the same torch-CPU operators; the reference itself cannot
-    travel to the GPU box) on ONE utterance of the batch, B = 1 like voicefixer/__main__.py:187-212, all host
-    threads: 1 warm-up + ``--cpu-reps`` timed repetitions, median reported."""
+    travel to the GPU box) on ONE utterance of the batch, B = 1 like voicefixer/__main__.py:187-212.
+    ATen's default thread count on a 2 x 64-core host oversubscribes this small-operator path, so the thread count is
+    TUNED first (a sweep on a 2 s clip of the same utterance) and the reported ``value`` is the median of
+    ``--cpu-reps`` repetitions of the full utterance at the best count; the all-threads figure (what
+    ``torch.set_num_threads(os.cpu_count())`` style defaults give) is reported beside it."""
     from oracle import oracle  # checker / reported baseline only -- never on the product path
     from voicefixer_amd import weights
     vsd, rsd = weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321)
-    threads = torch.get_num_threads()
-    times = []
+    default_threads = torch.get_num_threads()
+    clip = w1[: 2 * SR]
+
+    def timed(x, threads):
+        torch.set_num_threads(threads)
+        c0 = time.perf_counter()
+        y = oracle.restore_inmem(x, vsd, rsd)
+        return time.perf_counter() - c0, y
+
     with torch.no_grad():
-        oracle.restore_inmem(w1[: 2 * SR], vsd, rsd)  # thread-pool / allocator warm-up (2 s of audio)
+        timed(clip, default_threads)  # thread-pool / allocator warm-up
+        sweep = {}
+        for th in sorted({t for t in (4, 8, 16, 32, 64, default_threads) if t <= max(default_threads, 8)}):
+            timed(clip, th)
+            sweep[th] = round(timed(clip, th)[0], 3)
+        best = min(sweep, key=sweep.get)
+        times = []
         for _ in range(max(1, args.cpu_reps)):
-            c0 = time.perf_counter()
-            ref = oracle.restore_inmem(w1, vsd, rsd)
-            times.append(time.perf_counter() - c0)
+            dt, ref = timed(w1, best)
+            times.append(dt)
+        all_threads_s = timed(w1, default_threads)[0] if best != default_threads else None
+        torch.set_num_threads(default_threads)
     med = sorted(times)[len(times) // 2]
     err = float(torch.sqrt(torch.mean((gpu_out - torch.from_numpy(ref[0])) ** 2)))
-    return {"value": round(args.seconds / med, 3), "unit": "x real-time", "cores": threads, "kind": "port",
-            "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
-            "repetitions_s": [round(t, 2) for t in times],
-            "sample": "1 utterance of %.0f s (one utterance of the last timed batch), B=1 sequential like "
-                      "voicefixer/__main__.py:187-212; median of %d repetitions after one 2 s warm-up; %.1f s of CPU "
-                      "time in total" % (args.seconds, len(times), sum(times)),
-            "rms_vs_gpu": err}
+    out = {"value": round(args.seconds / med, 3), "unit": "x real-time", "cores": best, "kind": "port",
+           "cpu_model": cpu_model(), "os_cpu_count": os.cpu_count(), "torch": torch.__version__,
+           "repetitions_s": [round(t, 2) for t in times],
+           "thread_sweep_2s_clip_s": {str(k): v for k, v in sweep.items()},
+           "sample": "1 utterance of %.0f s (one utterance of the last timed batch), B=1 sequential like "
+                     "voicefixer/__main__.py:187-212, at the best thread count of a sweep over a 2 s clip; median of "
+                     "%d repetitions; %.1f s of CPU time for them" % (args.seconds, len(times), sum(times)),
+           "rms_vs_gpu": err}
+    if all_threads_s is not None:
+        out["all_threads"] = {"value": round(args.seconds / all_threads_s, 3), "cores": default_threads,
+                              "seconds": round(all_threads_s, 2)}
+    return out
 
 
 def host_to_host_leg(pipe, args, n, dev):
@@ -194,6 +224,8 @@ def scatter_job(args, pipe, n, rank, world, dev, dist):
                                    % (n_utt, args.seconds, per, args.batch),
                        "batch_per_gpu": args.batch, "utterances": n_utt, "utterance_seconds": args.seconds,
                        "parallelism": "utterance sharding x%d, RCCL point-to-point scatter/gather only" % world},
+            "requested_gpus": int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus)),
+            "visible_devices": torch.cuda.device_count(),
             "rccl": {"backend": dist.get_backend(), "world_size": dist.get_world_size()},
             "per_rank": [{"rank": r, "total_s": round(float(x[0]), 4), "scatter_s": round(float(x[1]), 4),
                           "compute_s": round(float(x[2]), 4), "gather_s": round(float(x[3]), 4)}
@@ -202,6 +234,62 @@ def scatter_job(args, pipe, n, rank, world, dev, dist):
         }
         print(json.dumps(line), flush=True)
     dist.destroy_process_group()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """``python bench.py --gpus N`` started WITHOUT a launcher (no WORLD_SIZE): become the launcher.  One process per
+    GPU under torch.distributed.run on 127.0.0.1, N clamped to the visible device count (loudly); the folder job this
+    scales is voicefixer/__main__.py:187-212 (the launcher runs unchanged on 1..8 visible devices)."""
+    visible = args.gpus if args.dry_run else torch.cuda.device_count()
+    nproc = max(1, min(args.gpus, visible))
+    if nproc < args.gpus:
+        print("bench.py: WARNING: --gpus %d requested but only %d HIP device(s) visible -> running %d rank(s); "
+              "n_gpus in the JSON line is the number of ranks that ran" % (args.gpus, visible, nproc),
+              file=sys.stderr, flush=True)
+    if nproc <= 1:
+        return False  # fall through to the single-process path (reports n_gpus = 1, requested_gpus = N)
+    env = dict(os.environ)
+    env["VFX_BENCH_REQUESTED_GPUS"] = str(args.gpus)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this host driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // (2 * nproc))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    sys.stdout.flush()
+    os.execve(sys.executable, cmd, env)
+
+
+def dry_run(args, rank, world):
+    """CPU rehearsal of the N-rank launch (tests/test_bench_launcher.py): gloo instead of RCCL, no device work --
+    what is exercised is the self-launch, the rendezvous, the barrier / max-over-ranks reduction and the JSON line."""
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    dt = torch.tensor([time.perf_counter() - t0, float(rank)], dtype=torch.float64)
+    allr = [torch.zeros_like(dt) for _ in range(world)]
+    if world > 1:
+        dist.barrier()
+        dist.all_gather(allr, dt)
+    else:
+        allr = [dt]
+    if rank == 0:
+        dmax = max(float(x[0]) for x in allr)
+        print(json.dumps({
+            "metric": "seconds-of-44.1kHz-audio restored per wall-second", "dry_run": True, "value": None,
+            "n_gpus": world, "requested_gpus": int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus)),
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dmax * 1e3, 3),
+            "rccl": {"backend": dist.get_backend() if world > 1 else None, "world_size": world},
+            "per_rank": [{"rank": int(x[1]), "device": "dry"} for x in allr]}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -224,15 +312,22 @@ def main():
     ap.add_argument("--scatter", action="store_true",
                     help="BASELINE configs[3]: rank 0 owns --utterances-per-gpu x N utterances, scatter/gather over RCCL")
     ap.add_argument("--utterances-per-gpu", type=int, default=256)
-    ap.add_argument("--cpu-reps", type=int, default=3, help="timed repetitions of the CPU baseline (median reported)")
+    ap.add_argument("--cpu-reps", type=int, default=2, help="timed repetitions of the CPU baseline (median reported)")
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32",
                     help="contraction arithmetic: exact fp32 MFMA (default, the headline) or the opt-in split-bf16 "
                          "products with fp32 accumulation (DESIGN.md 3.4)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="test hook: rehearse the N-rank launch on CPU (gloo, no device work)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])   # does not return when it re-executes under torch.distributed.run
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    requested = int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus))
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
@@ -246,7 +341,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
-    from voicefixer_amd import engine, ops, weights
+    from voicefixer_amd import engine, ops, weights, _lib
+    build_id = _lib.lib().vfx_build_id().decode()
 
     n = int(round(args.seconds * SR))
     pipe = engine.Pipeline(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321), dev, args.math)
@@ -299,10 +395,14 @@ def main():
     pipe.check()  # device-side error flags (two-CU GRU hand-off)
     last_idx = (args.steps - 1) % NRING  # ``out`` is the restoration of ring[last_idx]
 
+    per_rank = [{"rank": 0, "device": "cuda:%d" % dev.index, "wall_s": round(dt, 4)}]
     if dist is not None:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt, float(dev.index)], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "device": "cuda:%d" % int(x[1]), "wall_s": round(float(x[0]), 4)}
+                    for r, x in enumerate(allr)]
+        dt = max(float(x[0]) for x in allr)   # max over ranks
 
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
@@ -375,15 +475,23 @@ def main():
     achieved = 2.0 * macs * xf / secs / 1e12
     # HBM bytes per launch of that family: PMC counters cannot be read live; they come from the committed rocprofv3
     # --pmc passes over this same command (tools/profile_round.sh -> profiles/r02_pmc_hbm_traffic_bench_b32.json)
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic_bench_b32.json")
+    # -- and only when that summary was taken with THIS library: the summary carries vfx_build_id() of the build it
+    # profiled; a kernel change without a re-profile reports traffic = null and says why
+    traffic, traffic_note = None, None
+    tfile = os.path.join(ROOT, "profiles", TRAFFIC_PROFILE)
     if os.path.exists(tfile) and args.batch == 32 and abs(args.seconds - 10.0) < 1e-9:
-        num = den = 0
-        for kn, rec in json.load(open(tfile))["kernels"].items():
-            if re.search(krx, kn):
-                num += rec["hbm_bytes_per_launch"] * rec["launches"]
-                den += rec["launches"]
-        traffic = int(num / den) if den else None
+        doc = json.load(open(tfile))
+        if doc.get("lib_build_id") != build_id:
+            traffic_note = ("profiles/%s was taken with library build %s, the loaded library is %s: HBM traffic not "
+                            "reported (re-run tools/profile_round.sh)" % (TRAFFIC_PROFILE, doc.get("lib_build_id"), build_id))
+            print("bench.py: WARNING: " + traffic_note, file=sys.stderr, flush=True)
+        else:
+            num = den = 0
+            for kn, rec in doc["kernels"].items():
+                if re.search(krx, kn):
+                    num += rec["hbm_bytes_per_launch"] * rec["launches"]
+                    den += rec["launches"]
+            traffic = int(num / den) if den else None
     x3_dom = kname.startswith("conv_x3")
     # bf16x3 instance: three bf16 MFMA products per algorithmic product -> peak = dense bf16 peak / 3
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if x3_dom else FP32_MFMA_PEAK_TFLOPS
@@ -392,6 +500,7 @@ def main():
     roofline = {
         "bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
         "frac": round(achieved / peak, 4), "traffic": traffic,
+        **({"traffic_note": traffic_note} if traffic_note else {}),
         "kernel": kname, "kernel_name_regex": krx,
         "launches_per_step": launches // args.steps,
         "avg_launch_ms": round(secs / launches * 1e3, 4),
@@ -435,8 +544,15 @@ def main():
                                  else "opt-in split-bf16 products (three bf16 MFMAs per fp32 product), fp32 accumulation",
                    "parallelism": "utterance sharding x%d (no data-path collective)" % world},
         "path_tflops": round(2.0 * path_macs(n) * args.batch * world * args.steps / dt / 1e12, 2),
+        "requested_gpus": requested, "visible_devices": torch.cuda.device_count(),
+        "rccl": {"backend": dist.get_backend() if dist is not None else None, "world_size": world},
+        "per_rank": per_rank,
+        "lib_build_id": build_id,
         "roofline": roofline,
     }
+    if requested != world:
+        line["note_gpus"] = ("--gpus %d was requested, %d rank(s) ran (visible HIP devices: %d)"
+                             % (requested, world, torch.cuda.device_count()))
 
     if world == 1 and args.math == "f32" and not args.no_bf16x3:
         # auxiliary, NOT the headline: the same workload with the opt-in split-bf16 contraction (three bf16 MFMA
@@ -457,6 +573,9 @@ def main():
 
     if world == 1 and not args.no_host_leg:
         line["host_to_host"] = host_to_host_leg(pipe, args, n, dev)
+        # SURVEY.md 8(d)'s host-waveform -> host-waveform figure, at the top level next to `value` (which the bench
+        # contract defines with inputs resident in HBM)
+        line["value_host_to_host"] = line["host_to_host"]["value"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, ring[last_idx][0].cpu().numpy(), out[0].cpu())

@@ -109,6 +109,10 @@ typedef struct {
 
 int vfx_version(void);
 
+/* 16 hex digits: sha256 over every source file this library was built from (csrc/Makefile: BUILD_ID).  Measurement
+ * records (bench.py, profiles/ PMC summaries) carry it so that a profile can be tied to the library that produced it. */
+const char* vfx_build_id(void);
+
 /* Number of hipLaunchKernel calls issued by this library in this process (test hook:
  * proves the HIP path, not a fallback, produced a result). */
 uint64_t vfx_launch_count(void);

@@ -1,0 +1,45 @@
+"""bench.py launched PLAIN with --gpus N must start N ranks by itself (SURVEY.md 8(e) caveat: "the launcher must run
+unchanged on 1...8 visible devices and print the device count").  Rehearsed on CPU: --dry-run swaps RCCL for gloo and
+skips the device work; the self-launch, rendezvous on 127.0.0.1, barrier and JSON line are the real code."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra, env=None):
+    e = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2", "--warmup", "1",
+                        *extra], capture_output=True, text=True, timeout=300, env=e)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout       # rank 0 prints ONE JSON line
+    return json.loads(lines[0]), r.stderr
+
+
+def test_plain_launch_with_gpus_2_runs_two_ranks():
+    line, _ = _run("--gpus", "2")
+    assert line["n_gpus"] == 2 and line["requested_gpus"] == 2
+    assert line["rccl"]["world_size"] == 2 and line["rccl"]["backend"] == "gloo"
+    assert sorted(r["rank"] for r in line["per_rank"]) == [0, 1]
+
+
+def test_plain_launch_single():
+    line, _ = _run("--gpus", "1")
+    assert line["n_gpus"] == 1 and line["per_rank"] == [{"rank": 0, "device": "dry"}]
+
+
+def test_under_an_external_launcher_the_script_does_not_relaunch():
+    # the driver's form: WORLD_SIZE already set by torch.distributed.run -> bench.py must use it, not nest a launcher
+    line, _ = _run("--gpus", "8", env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert line["n_gpus"] == 1 and line["requested_gpus"] == 8
+
+
+def test_gpus_flag_is_read():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "args.gpus" in src and "torch.distributed.run" in src

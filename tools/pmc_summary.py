@@ -12,8 +12,20 @@ mfma: mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 X
 """
 import csv
 import json
+import os
 import sys
 from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def build_id():
+    """vfx_build_id() of the in-tree library the profiled command loaded (bench.py refuses a stale summary)."""
+    try:
+        from voicefixer_amd import _lib
+        return _lib.lib().vfx_build_id().decode()
+    except Exception as e:  # noqa: BLE001 - a summary without a stamp is still a summary
+        return "unknown (%s)" % e
 
 
 def read(path):
@@ -39,6 +51,7 @@ def hbm(fetch_csv, write_csv, out):
         res[k] = {"launches": nf[k], "FETCH_SIZE_KB_avg": fa, "WRITE_SIZE_KB_avg": wa,
                   "hbm_bytes_per_launch": int((2 * fa + wa) * 1024)}
     doc = {
+        "lib_build_id": build_id(),
         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace -- "
                    "python bench.py --steps 1 --warmup 1 --batch 32 --no-cpu-baseline",
         "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide (16 B/lane) coalesced loads "
@@ -69,6 +82,7 @@ def mfma(m_csv, out):
             "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
         }
     doc = {
+        "lib_build_id": build_id(),
         "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
                    "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -- python bench.py --steps 1 "
                    "--warmup 1 --batch 32 --no-cpu-baseline",

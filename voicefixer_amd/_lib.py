@@ -41,6 +41,7 @@ _I = C.c_int
 # name -> (restype, argtypes); must list every symbol declared in include/vfx_hip.h
 SIGNATURES = {
     "vfx_version": (_I, []),
+    "vfx_build_id": (C.c_char_p, []),
     "vfx_launch_count": (C.c_uint64, []),
     "vfx_last_conv_tile": (_I, []),
     "vfx_conv1d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _I, _A, _P]),

@@ -7,6 +7,10 @@
 std::atomic<uint64_t> g_vfx_launches{0};
 
 extern "C" int vfx_version(void) { return 100; }
+#ifndef VFX_BUILD_ID
+#define VFX_BUILD_ID "unstamped"
+#endif
+extern "C" const char* vfx_build_id(void) { return VFX_BUILD_ID; }
 extern "C" uint64_t vfx_launch_count(void) { return g_vfx_launches.load(); }
 
 // --------------------------------------------------------------------------------------
