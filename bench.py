@@ -436,10 +436,10 @@ def main():
         if code in (70, 79):
             wgm = bm // 32
             if code == 79:
-                return ("wino2d", bm, bl), "convwg_kernel<%d,%d,false,3> (3x3 as Winograd F(2,3) along the map rows)" % (
-                    wgm, 4 // wgm), r"convwg_kernel<%d, %d, false, 3, \d+>" % (wgm, 4 // wgm)
-            return ("wino", bm, bl), "convwg_kernel<%d,%d,*,1> (Winograd F(2,3), %d ch x %d output pairs)" % (
-                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d, (true|false), 1, \d+>" % (wgm, 4 // wgm)
+                return ("wino2d", bm, bl), "convwg_kernel<%d,%d,3> (3x3 as Winograd F(2,3) along the map rows)" % (
+                    wgm, 4 // wgm), r"convwg_kernel<%d, %d, 3, \d+>" % (wgm, 4 // wgm)
+            return ("wino", bm, bl), "convwg_kernel<%d,%d,1> (Winograd F(2,3), %d ch x %d output pairs)" % (
+                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d, 1, \d+>" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \

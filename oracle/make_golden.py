@@ -20,6 +20,16 @@ Fixtures
                           (vocoder/config.py:161-290) and the constants (a, b) of its analytic fit
                           (config.py:300-316): the reciprocal slaney area normalisation of librosa.filters.mel,
                           used to pin oracle/librosa_like.mel_basis (python oracle/make_golden.py --constants)
+  mode1_speech_ref.npz    the reference's OWN VoiceFixer.remove_higher_frequency (base.py:87-104) and restore_inmem(mode=1)
+                          on 0.75 s of the reference's test utterance, executed through ref_shim with librosa's three
+                          transforms bound to oracle/librosa_like: ``hf_cut`` (the pre-filtered waveform), ``restored``
+  vocoder_oracle_ref.npz  the reference's OWN Vocoder.oracle (vocoder/base.py:58-77) on 1 s of its fixture
+                          test/utterance/original/p360_001_mic1.flac: PCM16 input, the conditioning its numpy front-end
+                          builds (``cond``), and the int16 frames it hands to soundfile.write (``out_pcm``)
+  ref_utterance/          the reference's test utterances and FLAC goldens (test/utterance/original/*.flac,
+                          target/{oracle,output_mode_0,output_mode_1}.flac) copied verbatim: inputs / targets of the
+                          real-checkpoint harness (tests/test_real_checkpoints.py = test/test.py:27-95) and, together with
+                          ``flac_original_pcm.npz`` (the PCM of original.wav), known answers for voicefixer_amd/flac.py
 """
 import hashlib
 import os
@@ -133,6 +143,52 @@ def main():
     run_vocoder(mel, "vocoder_T101.npz")
     mel = 10 ** (torch.rand((2, 1, 24, 128), generator=g) * 5 - 2)
     run_vocoder(mel, "vocoder_B2_T24.npz")
+
+    # ---- the librosa legs, executed from the reference's own code (ref_shim binds librosa.stft / istft / filters.mel
+    # to oracle/librosa_like; everything else on these lines is the reference's numpy / torch code, unmodified)
+    seg = (pcm[30000:30000 + 33075].astype(np.float32) / 32768.0)          # 0.75 s of the reference's utterance
+    with torch.no_grad():
+        hf = vf.remove_higher_frequency(seg)                                # base.py:87-104
+        restored1 = vf.restore_inmem(seg, cuda=False, mode=1)               # base.py:107-139 with mode == 1
+    assert hf.shape == (512 * (len(seg) // 512),) and restored1.shape == (1, hf.shape[0])
+    np.savez_compressed(os.path.join(OUT, "mode1_speech_ref.npz"), wav=seg, hf_cut=hf.astype(np.float32),
+                        restored=restored1, voc_seed=VOC_SEED, res_seed=RES_SEED)
+    print("mode1_speech_ref", seg.shape, "->", restored1.shape)
+
+    from voicefixer_amd import flac
+    import soundfile as sf_stub                                             # (the ref_shim stub: records sf.write calls)
+    rate, p360, bps = flac.read(os.path.join(ref_shim.REFERENCE_ROOT, "test/utterance/original/p360_001_mic1.flac"))
+    assert rate == 44100 and bps == 16 and p360.shape[1] == 1
+    pcm_in = p360[20000:20000 + 44100, 0].astype(np.int16)
+    tmp_in = os.path.join(home, "oracle_in.wav")
+    wavfile.write(tmp_in, 44100, pcm_in)
+    sf_stub.written.clear()
+    voc = vf._model.vocoder
+    voc.oracle(fpath=tmp_in, out_path=os.path.join(home, "oracle_out.wav"), cuda=False)   # vocoder/base.py:58-77
+    (_, frames, rate_out), = sf_stub.written
+    assert rate_out == 44100 and frames.dtype == np.int16
+    # the conditioning tensor its numpy front-end built (same calls, same order as vocoder/base.py:61-71)
+    from voicefixer.vocoder.model.util import linear_to_mel, normalize, amp_to_db, pre
+    from voicefixer.tools.wav import read_wave
+    from voicefixer.vocoder.config import Config
+    import librosa as librosa_stub
+    w = read_wave(tmp_in, sample_rate=44100)[..., 0]
+    w = w / np.max(np.abs(w))
+    st = np.abs(librosa_stub.stft(w, hop_length=Config.hop_length, win_length=Config.win_size, n_fft=Config.n_fft))
+    cond = pre(np.transpose(normalize(amp_to_db(np.abs(linear_to_mel(st))) - 20), (1, 0)))
+    np.savez_compressed(os.path.join(OUT, "vocoder_oracle_ref.npz"), pcm_in=pcm_in, cond=cond.numpy(),
+                        out_pcm=frames.reshape(-1), voc_seed=VOC_SEED)
+    print("vocoder_oracle_ref", pcm_in.shape, "cond", tuple(cond.shape), "->", frames.shape)
+
+    # ---- the reference's FLAC fixtures, verbatim (data, not source), + the PCM known answer for the decoder
+    import shutil
+    dst = os.path.join(OUT, "ref_utterance")
+    os.makedirs(dst, exist_ok=True)
+    for rel in ("original/original.flac", "original/p360_001_mic1.flac", "target/oracle.flac",
+                "target/output_mode_0.flac", "target/output_mode_1.flac"):
+        shutil.copyfile(os.path.join(ref_shim.REFERENCE_ROOT, "test/utterance", rel),
+                        os.path.join(dst, rel.replace("/", "_")))
+    np.savez_compressed(os.path.join(OUT, "flac_original_pcm.npz"), pcm=pcm)   # == original.wav, PCM16
 
 
 if __name__ == "__main__":

@@ -113,15 +113,63 @@ def install_stubs():
     def _unavailable(*a, **k):
         raise RuntimeError("librosa is stubbed: this call is outside the parity path")
 
-    librosa.load = _unavailable
-    librosa.stft = _unavailable
-    librosa.istft = _unavailable
-    filters.mel = _unavailable
+    # The three librosa transforms on the path are bound to oracle/librosa_like (restated from librosa's published
+    # algorithms, pinned against scipy.signal and reference-held constants by tests/test_librosa_like.py), with
+    # librosa's own signatures and defaults.  With them the REFERENCE'S OWN numpy code runs unmodified in this
+    # container: VoiceFixer.remove_higher_frequency (base.py:87-104, mode 1) and the front half of Vocoder.oracle
+    # (vocoder/base.py:58-77 + model/util.py:39-66,83-94,115-128) -- oracle/make_golden.py turns their outputs into
+    # fixtures.  Anything else librosa offers stays unavailable and raises.
+    from oracle import librosa_like as ll
+
+    def _stft(y, n_fft=2048, hop_length=None, win_length=None, window="hann", center=True, dtype=None,
+              pad_mode="constant"):
+        assert n_fft == ll.N_FFT and win_length in (None, n_fft) and window == "hann" and center
+        assert pad_mode == "constant"   # librosa >= 0.10 default (the reference's Dockerfile pins 0.10.1)
+        return ll.stft(y, hop_length if hop_length is not None else n_fft // 4)
+
+    def _istft(stft_matrix, hop_length=None, win_length=None, n_fft=None, window="hann", center=True, dtype=None,
+               length=None):
+        assert stft_matrix.shape[0] == ll.N_FFT // 2 + 1 and window == "hann" and center and length is None
+        return ll.istft(stft_matrix, hop_length if hop_length is not None else ll.N_FFT // 4)
+
+    def _mel(sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False, norm="slaney", dtype=np.float32):
+        assert (sr, n_fft, n_mels, fmin, htk, norm) == (ll.SR, ll.N_FFT, ll.N_MELS, 0, True, "slaney")
+        assert fmax in (None, ll.SR // 2, ll.SR / 2.0)
+        return ll.mel_basis()
+
+    def _load(path, sr=22050, mono=True, offset=0.0, duration=None, **kw):
+        """librosa.load for files ALREADY at ``sr`` (no resampler here): float32 in [-1, 1], (n,) or (channels, n)."""
+        assert offset == 0.0 and duration is None
+        low = str(path).lower()
+        if low.endswith(".flac"):
+            from voicefixer_amd import flac
+            rate, pcm, bps = flac.read(path)
+            x = pcm.astype(np.float32).T / float(1 << (bps - 1))
+        else:
+            from scipy.io import wavfile
+            rate, data = wavfile.read(path)
+            assert data.dtype == np.int16
+            x = (data.astype(np.float32) / 32768.0).T
+        assert rate == sr, "the shimmed librosa.load does not resample"
+        if x.ndim == 2 and (mono or x.shape[0] == 1):
+            x = x.mean(axis=0) if x.shape[0] > 1 else x[0]
+        return np.ascontiguousarray(x), rate
+
+    librosa.load = _load
+    librosa.stft = _stft
+    librosa.istft = _istft
+    filters.mel = _mel
     display.specshow = _unavailable
 
     sf = mod("soundfile")
-    sf.write = _unavailable
+    sf.written = []                      # (fname, frames, samplerate) of every soundfile.write the reference issued
+
+    def _sf_write(fname, frames, samplerate=44100, **kw):
+        sf.written.append((fname, np.array(frames, copy=True), samplerate))
+
+    sf.write = _sf_write
     sf.read = _unavailable
+    sf.available_formats = lambda: {"WAV": "WAV (Microsoft)", "FLAC": "FLAC (Free Lossless Audio Codec)"}
 
     tl = mod("torchlibrosa")
     tls = mod("torchlibrosa.stft")

@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 
 from voicefixer_amd import ops, packing, _lib  # noqa: E402
 from oracle import oracle  # noqa: E402  (checker only)
+from conftest import GOLDEN  # noqa: E402
 
 DEV = "cuda"
 
@@ -318,20 +319,6 @@ def test_conv1d_winograd(case):
         ops.conv1d(xd, wp.to(DEV), bias.to(DEV), rd2, L, 3, dil, 0, act, rd2, wg=wg)
         torch.cuda.synchronize()
         _close(rd2[:, :, :L], ref, 2e-5)
-    if dil == 1:
-        # with a guard band dilation 1 takes the contiguous-tap instance (one 16-byte load per pair and channel,
-        # 8-byte residual loads / stores; the vector of an edge pair reaches into the guard: NaN there must not leak)
-        xg = _guarded_nan(x, 8)
-        yd2 = torch.full((B, Cout, lp), float("nan"), device=DEV)
-        os.environ["VFX_WINO_D1"] = "1"            # (opt-in instance, the switch is read per launch)
-        try:
-            ops.conv1d(xg, wp.to(DEV), bias.to(DEV), yd2, L, 3, dil, 0, act, _padded(res, lp) if use_res else None, wg=wg)
-            torch.cuda.synchronize()
-        finally:
-            del os.environ["VFX_WINO_D1"]
-        assert _lib.lib().vfx_last_conv_tile() % 100 == 70
-        _close(yd2[:, :, :L], ref, 2e-5)
-        assert torch.isnan(yd2[:, :, L:]).all()
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
@@ -404,17 +391,12 @@ def test_conv1d_winograd_ragged_rows_and_fallback():
     wp = packing.pack_conv1d(w)
     wg = packing.pack_wino(wp).to(DEV)
     act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01)
-    for dil, d1 in ((27, False), (1, False), (1, True)):   # (d1: the opt-in contiguous-tap instance of dilation 1)
+    for dil in (27, 1):
         xd = _guarded_nan(x, 8)
         yd = torch.full((B, C, L + 60), float("nan"), device=DEV)
         ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
-        if d1:
-            os.environ["VFX_WINO_D1"] = "1"
-        try:
-            ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg=wg)
-            torch.cuda.synchronize()
-        finally:
-            os.environ.pop("VFX_WINO_D1", None)
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg=wg)
+        torch.cuda.synchronize()
         assert _lib.lib().vfx_last_conv_tile() % 100 == 70
         for r, n in enumerate(lens):
             ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
@@ -1114,3 +1096,14 @@ def test_conv1d_randomised_geometry_sweep():
                 case, B, Cin, Cout, L, k, dil, guarded, use_res, inplace, x3, err)
         if not inplace:
             assert torch.isnan(yd[:, :, L:]).all(), "case %d wrote past L" % case
+
+
+def test_hf_cut_against_the_reference_executed_fixture():
+    """vfx_hf_cut_f32 vs VoiceFixer.remove_higher_frequency EXECUTED from the reference's code (base.py:87-104; fixture
+    tests/golden/mode1_speech_ref.npz, oracle/make_golden.py through ref_shim) on 0.75 s of the reference's utterance."""
+    g = np.load(os.path.join(GOLDEN, "mode1_speech_ref.npz"))
+    wav = torch.from_numpy(g["wav"])[None].to(DEV)
+    out, cut = ops.hf_cut(wav, wav.shape[1], 0.95)
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == (1,) + g["hf_cut"].shape
+    assert np.abs(out[0].cpu().numpy() - g["hf_cut"]).max() < 2e-5

@@ -99,3 +99,33 @@ def test_int16_truncation():
     x = np.array([[0.5, -0.5, 0.99999, -1.0, 1e-5]], dtype=np.float32)
     q = oracle.to_int16(x)
     assert q.dtype == np.int16 and list(q[0]) == [16384, -16384, 32767, -32768, 0]
+
+
+def test_mode1_against_the_references_own_remove_higher_frequency(seeded_states):
+    """mode1_speech_ref.npz = VoiceFixer.remove_higher_frequency / restore_inmem(mode=1) EXECUTED from the reference's
+    code (base.py:87-104,121-122) through ref_shim; the oracle's restatement must reproduce both."""
+    g = _load("mode1_speech_ref.npz")
+    filt, cut = oracle.remove_higher_frequency(g["wav"])
+    assert filt.shape == g["hf_cut"].shape == (512 * (len(g["wav"]) // 512),) and 0 < cut < 1025
+    assert np.abs(filt - g["hf_cut"]).max() < 1e-6
+    with torch.no_grad():
+        out = oracle.restore_inmem(filt, *seeded_states)
+    assert out.shape == g["restored"].shape
+    assert np.sqrt(np.mean((out - g["restored"]) ** 2)) < 1e-5
+
+
+def test_vocoder_oracle_against_the_references_own_front_end(seeded_states):
+    """vocoder_oracle_ref.npz = Vocoder.oracle EXECUTED from the reference's code (vocoder/base.py:58-77): the
+    conditioning its numpy front-end builds and the int16 frames it hands to soundfile.write."""
+    from oracle import librosa_like
+    g = _load("vocoder_oracle_ref.npz")
+    wav = g["pcm_in"].astype(np.float32) / 32768.0
+    cond = librosa_like.wav_to_cond(wav)
+    T = 1 + len(wav) // 441
+    assert tuple(cond.shape) == g["cond"].shape == (1, 128, T + T % 2 + 4)      # (pre() appends the tail frames)
+    assert np.abs(cond.numpy() - g["cond"]).max() < 1e-5
+    with torch.no_grad():
+        y = oracle.vocoder_generator(cond, seeded_states[0])
+    pcm = oracle.to_int16((y[0] * 2 ** 15).numpy())[0]
+    assert pcm.shape == g["out_pcm"].shape
+    assert np.abs(pcm.astype(np.int32) - g["out_pcm"].astype(np.int32)).max() <= 1   # truncation of ~1e-6 differences

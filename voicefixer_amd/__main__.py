@@ -1,0 +1,139 @@
+#!/usr/bin/env python
+"""Command line of the MI355X VoiceFixer path: ``python -m voicefixer_amd`` == the reference's ``voicefixer`` console
+script (voicefixer/__main__.py:69-215): same flags (``-i/-o/-ifdr/-ofdr/--mode/--disable-cuda/--silent/
+--weight_prepare``), same argument checks and messages, same ``<name>-mode<k><ext>`` naming for ``--mode all``.
+
+Differences, all deliberate:
+  * folder mode (``--infolder``) does not loop files at B = 1 (``__main__.py:187-212``) but hands the folder to
+    ``VoiceFixer.restore_folder``: length-sorted ragged batches, decode || restore || encode pipelined;
+  * ``--disable-cuda`` cannot move compute to the CPU (there is no CPU implementation in this package): it is accepted and
+    only selects host tensors at the API boundary, exactly like ``cuda=False`` everywhere else in voicefixer_amd;
+  * mode 2 (train-mode BatchNorm + Dropout) is not built: ``--mode 2`` raises NotImplementedError, ``--mode all`` writes
+    modes 0 and 1 and says that mode 2 was skipped;
+  * ``--weight_prepare`` cannot download (no network): it only reports whether both checkpoints are in place;
+  * output formats are WAV and FLAC (``audio_io.FORMATS``) instead of whatever libsndfile offers.
+"""
+import argparse
+import os
+import re
+import sys
+import time
+
+MODES_BUILT = (0, 1)
+
+
+def check_output_format(outfile):
+    """voicefixer/__main__.py:30-33 with soundfile.available_formats() replaced by what audio_io can write."""
+    from . import audio_io
+    fmt = re.search(r"\.(\w+)$", outfile)
+    assert fmt is not None, "Error: A file-extension for the outfile is missing."
+    assert "." + fmt.groups()[0].lower() in audio_io.FORMATS, "Error: Unsupported output format."
+
+
+def check_arguments(args):
+    """voicefixer/__main__.py:36-66."""
+    process_file, process_folder = len(args.infile) != 0, len(args.infolder) != 0
+    assert process_file or process_folder, (
+        "Error: You need to specify a input file path (--infile) or a input folder path (--infolder) to proceed. "
+        "For more information please run: voicefixer -h")
+    if process_file:
+        assert os.path.exists(args.infile), "Error: The input file %s is not found." % args.infile
+        output_dirname = os.path.dirname(args.outfile)
+        if len(output_dirname) > 1:
+            os.makedirs(output_dirname, exist_ok=True)
+        check_output_format(args.outfile)
+    if process_folder:
+        assert os.path.exists(args.infolder), "Error: The input folder %s is not found." % args.infolder
+        if len(args.outfolder) > 1:
+            os.makedirs(args.outfolder, exist_ok=True)
+    return process_file, process_folder
+
+
+def mode_outfile(outfile, mode, append_mode):
+    """voicefixer/__main__.py:13-18: ``<dir>/<base>-mode<k><ext>`` when several modes write next to each other."""
+    if not append_mode:
+        return outfile
+    base, ext = os.path.splitext(os.path.basename(outfile))
+    return os.path.join(os.path.dirname(outfile), "{}-mode{}{}".format(base, mode, ext))
+
+
+def writefile(voicefixer, infile, outfile, mode, append_mode, cuda, verbose=False):
+    outfile = mode_outfile(outfile, mode, append_mode)
+    if verbose:
+        print("Processing {}, mode={}".format(infile, mode))
+    start = time.time()
+    voicefixer.restore(input=infile, output=outfile, cuda=cuda, mode=int(mode))
+    print("Restoration took {} s".format(round(time.time() - start, 1)))
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(prog="voicefixer_amd", description="VoiceFixer - restores degraded speech (MI355X path)")
+    parser.add_argument("-i", "--infile", type=str, default="", help="An input file to be processed by VoiceFixer.")
+    parser.add_argument("-o", "--outfile", type=str, default="outfile.wav", help="An output file to store the result.")
+    parser.add_argument("-ifdr", "--infolder", type=str, default="",
+                        help="Input folder. Place all your wav file that need process in this folder.")
+    parser.add_argument("-ofdr", "--outfolder", type=str, default="outfolder",
+                        help="Output folder. The processed files will be stored in this folder.")
+    parser.add_argument("--mode", choices=["0", "1", "2", "all"], default="0",
+                        help="0: Original Model (default), 1: Add preprocessing module (remove higher frequencies), "
+                             "2: Train mode (not built in this package), all: one output per built mode (0 and 1).")
+    parser.add_argument("--disable-cuda", default=False, action="store_true",
+                        help="Accepted for compatibility: compute always runs on the MI355X, results are handed over on the host.")
+    parser.add_argument("--silent", default=False, action="store_true",
+                        help="Set this flag if you do not want to see any message.")
+    parser.add_argument("--weight_prepare", default=False, action="store_true",
+                        help="Only check that both checkpoints are in place (no network here: nothing is downloaded).")
+    parser.add_argument("--batch-size", type=int, default=32, help="(extension) files per ragged batch in folder mode")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.weight_prepare:
+        from . import api
+        home = os.path.expanduser("~")
+        missing = [p for p in (api.ANALYSIS_CKPT, api.VOCODER_CKPT) if not os.path.exists(os.path.join(home, p))]
+        if missing and not args.silent:
+            print("Missing checkpoint(s) under ~: %s (no network in this build: place the Zenodo files there)" % ", ".join(missing))
+        return 1 if missing else 0
+    process_file, process_folder = check_arguments(args)
+    if process_file:
+        audioext = os.path.splitext(os.path.basename(args.infile))[-1]
+        if audioext.lower() not in (".wav", ".flac"):   # (the reference accepts .wav only; FLAC is what its own test reads)
+            raise ValueError("Error: Error processing the input file. We only support the .wav format currently. "
+                             "Please convert your %s format to .wav. Thanks." % audioext)
+    if args.mode == "2":
+        raise NotImplementedError("mode 2 (train-mode BatchNorm + Dropout, voicefixer/base.py:114-115) is nondeterministic "
+                                  "and not built in voicefixer_amd; modes 0 and 1 are")
+    import torch
+    from .api import VoiceFixer
+    cuda = bool(torch.cuda.is_available() and not args.disable_cuda)
+    if not args.silent:
+        print("Initializing VoiceFixer")
+    voicefixer = VoiceFixer()
+    if not args.silent:
+        print("Start processing the input file %s." % args.infile)
+    modes = list(MODES_BUILT) if args.mode == "all" else [int(args.mode)]
+    append = args.mode == "all"
+    if append and not args.silent:
+        print("--mode all: writing modes 0 and 1 (mode 2 is not built in this package)")
+    if process_file:
+        for m in modes:
+            writefile(voicefixer, args.infile, args.outfile, m, append, cuda, verbose=not args.silent)
+    if process_folder:
+        n_files = len([f for f in os.listdir(args.infolder) if os.path.splitext(os.path.basename(f))[-1] == ".wav"])
+        if not args.silent:
+            print("Found %s .wav files in the input folder %s. Start processing." % (n_files, args.infolder))
+        for m in modes:
+            start = time.time()
+            voicefixer.restore_folder(args.infolder, args.outfolder, mode=m, batch_size=args.batch_size,
+                                      name_suffix="-mode%d" % m if append else "")
+            if not args.silent:
+                print("Restoration of %d files (mode %d) took %s s" % (n_files, m, round(time.time() - start, 1)))
+    if not args.silent:
+        print("Done")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

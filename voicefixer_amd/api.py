@@ -186,14 +186,18 @@ class _RestorerHandle(nn.Module):
         return self._owner._vocoder
 
     def train(self, mode=True):
-        if mode:
-            raise NotImplementedError("mode 2 (BatchNorm in train mode, base.py:115) is nondeterministic and not built")
-        return super().train(False)
+        """nn.Module.train() recurses into children, so ``vf.train()`` / ``vf.eval()`` on the owning VoiceFixer (or any
+        wrapper that toggles modes) must not raise here: the flag is stored, and asking for a forward pass in train mode
+        (the reference's mode 2, base.py:115) is what fails."""
+        return super().train(mode)
 
     @torch.no_grad()
     def forward(self, sp, mel_orig):
         """mel_orig: [B, 1, T, 128] linear mel -> {"mel": log10 of the restored mel [B, 1, T, 128], "clean", "noisy"};
         ``sp`` is ignored exactly as in the reference (restorer/model.py:102: the argument is unused)."""
+        if self.training:
+            raise NotImplementedError("mode 2 (BatchNorm / Dropout in train mode, base.py:115) is nondeterministic and "
+                                      "not built; call .eval() first")
         assert mel_orig.size()[-1] == 128
         pipe = self._owner._get_pipe()
         m = mel_orig.detach().to(pipe.device, torch.float32)[:, 0].contiguous()
@@ -321,16 +325,21 @@ class VoiceFixer(nn.Module):
         return pipe.restore(seg, n, your_vocoder_func)
 
     @torch.no_grad()
-    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=2, ragged_ratio=0.5):
+    def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=2, ragged_ratio=0.5, mode=0):
         """Batched folder inference (not in the reference, which loops files at B=1,
-        voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i).
+        voicefixer/__main__.py:187-212): list of float32 numpy (N_i,) -> list of (1, N_i)  (mode 1: (1, 512*(N_i//512))
+        per 30 s segment, as ``restore_inmem`` returns it).
         Utterances of up to 30 s go through RAGGED batches: the length-sorted list is cut into runs of up to
         ``batch_size`` files whose shortest member has at least ``ragged_ratio`` of the frames of the longest, and a run
         is ONE launch sequence in which every kernel takes the per-row lengths (Pipeline.restore_rows) -- each row is
         what restoring that utterance alone returns, the tiles past a row's end are skipped, only the buffers are
         sized for the longest row.  Longer files (several 30 s segments) and plugin vocoders are bucketed by exact
         length, one batched launch sequence per segment index.  Batches go round-robin to ``streams`` HIP streams: the
-        low-occupancy phases of one batch (GRU recurrence, deep UNet levels) overlap the convolutions of the next."""
+        low-occupancy phases of one batch (GRU recurrence, deep UNet levels) overlap the convolutions of the next.
+        ``mode=1``: every file (every 30 s segment of it) first goes through the device-side high-frequency cut
+        (base.py:121-122, ``vfx_hf_cut_f32``) exactly as ``restore_inmem(mode=1)`` does it."""
+        from . import ops
+        self._check_mode(mode)
         pipe = self._get_pipe()
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
@@ -342,33 +351,53 @@ class VoiceFixer(nn.Module):
         while len(self._stream_pool) < max(1, int(streams)):
             self._stream_pool.append(torch.cuda.Stream(device=pipe.device))
         pool = self._stream_pool[:max(1, int(streams))]
-        pipe.set_streams(len(pool))
         main = torch.cuda.current_stream(pipe.device)
         for st in pool:
             st.wait_stream(main)
-        pending = []
-        for nb, (kind, grp) in enumerate(plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio,
-                                                     ragged=your_vocoder_func is None)):
-            grp = [order[g] for g in grp]
-            with torch.cuda.stream(pool[nb % len(pool)]):
-                if kind == "ragged":
-                    lens = [len(wavs[k]) for k in grp]
-                    seg = np.zeros((len(grp), max(lens)), np.float32)
-                    for r, k in enumerate(grp):
-                        seg[r, :lens[r]] = np.asarray(wavs[k], np.float32)
-                    full = pipe.restore_rows(torch.from_numpy(seg).to(pipe.device), lens)
-                    pending.append((grp, lens, full))
-                else:
-                    n = len(wavs[grp[0]])
-                    parts = []
-                    for s0 in range(0, n, SEG_LENGTH):
-                        seg = np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH] for k in grp])
-                        parts.append(pipe.restore(torch.from_numpy(seg).to(pipe.device, non_blocking=False),
-                                                  seg.shape[1], your_vocoder_func))
-                    full = torch.cat(parts, -1)
-                    pending.append((grp, [full.shape[-1]] * len(grp), full))
-        torch.cuda.synchronize(pipe.device)
-        pipe.set_streams(1)
+        pending, staging = [], []
+        pipe.set_streams(len(pool))
+        try:
+            for nb, (kind, grp) in enumerate(plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio,
+                                                         ragged=your_vocoder_func is None)):
+                grp = [order[g] for g in grp]
+                with torch.cuda.stream(pool[nb % len(pool)]):
+                    if kind == "ragged":
+                        lens = [len(wavs[k]) for k in grp]
+                        # rows are padded in a PINNED staging buffer (torch caches pinned blocks) and uploaded without
+                        # blocking the host, so that the next batch is staged while this one's copy and kernels run
+                        host = torch.zeros((len(grp), max(lens)), dtype=torch.float32, pin_memory=True)
+                        hv = host.numpy()
+                        for r, k in enumerate(grp):
+                            hv[r, :lens[r]] = wavs[k]
+                        seg = host.to(pipe.device, non_blocking=True)
+                        staging.append(host)    # stays alive until the device has been synchronised below
+                        if mode == 1:
+                            cut = torch.zeros_like(seg)
+                            for r in range(len(grp)):          # the cut-off is a per-file quantity (base.py:87-104)
+                                y, _ = ops.hf_cut(seg[r:r + 1, :lens[r]], lens[r], 0.95)
+                                lens[r] = y.shape[1]
+                                cut[r, :lens[r]] = y[0]
+                            seg = cut[:, :max(lens)].contiguous()
+                        full = pipe.restore_rows(seg, lens)
+                        pending.append((grp, lens, full))
+                    else:
+                        n = len(wavs[grp[0]])
+                        parts = []
+                        for s0 in range(0, n, SEG_LENGTH):
+                            host = torch.from_numpy(np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH]
+                                                              for k in grp])).pin_memory()
+                            staging.append(host)
+                            parts.append(self._restore_segments(pipe, host.to(pipe.device, non_blocking=True),
+                                                                host.shape[1], mode, your_vocoder_func))
+                        full = torch.cat(parts, -1)
+                        pending.append((grp, [full.shape[-1]] * len(grp), full))
+        finally:
+            # whatever happened (a too-short file, an out-of-memory, a plugin vocoder error): drain the side streams
+            # before the staging buffers go away, give the GRU its single-stream launch size back, and read the
+            # device-side error flag HERE so that a later, unrelated call does not inherit it
+            torch.cuda.synchronize(pipe.device)
+            pipe.set_streams(1)
+            del staging
         pipe.check()
         for grp, lens, full in pending:
             full = full.cpu().numpy()
@@ -384,18 +413,22 @@ class VoiceFixer(nn.Module):
         ``chunk_seconds - overlap_seconds``, each restored independently (equal-length chunks are batched),
         consecutive chunks cross-faded linearly over the overlap.  ``on_chunk(start, samples)`` is called with every
         finished stretch of output in order (bounded latency: the first call comes after the first batch).
-        Returns float32 numpy (1, N)."""
+        ``mode=1``: the high-frequency cut (base.py:121-122) runs per chunk; it returns 512 * (len // 512) samples
+        aligned at the chunk's start, so the chunk length is rounded down to a multiple of 512 (every full chunk keeps
+        its length) and only the last chunk loses its sub-512 tail -- the output is that much shorter, as the
+        reference's mode-1 output is.  Returns float32 numpy (1, N')."""
         self._check_mode(mode)
-        if mode != 0:
-            raise NotImplementedError("restore_stream implements mode 0 (mode 1 changes the chunk length)")
         pipe = self._get_pipe()
         wav = np.asarray(wav, dtype=np.float32)
         n = wav.shape[0]
         chunk, ov = int(round(chunk_seconds * 44100)), int(round(overlap_seconds * 44100))
+        if mode == 1:
+            chunk -= chunk % 512
         plan = plan_stream_chunks(n, chunk, ov)
         out = np.zeros((1, n), np.float32)
         fade_in = (np.arange(ov, dtype=np.float32) / max(ov, 1))[None]
         done = 0  # output is final below this sample
+        n_out = n
         i = 0
         while i < len(plan):
             length = plan[i][1]
@@ -403,33 +436,39 @@ class VoiceFixer(nn.Module):
             seg = torch.from_numpy(np.stack([wav[a:a + length] for a, _ in grp])).to(pipe.device)
             res = self._restore_segments(pipe, seg, length, mode, your_vocoder_func).cpu().numpy()
             pipe.check()
+            got = res.shape[1]          # == length in mode 0; 512 * (length // 512) in mode 1
             for (a, _), y in zip(grp, res):
                 y = y[None]
                 if a > 0:  # cross-fade with what the previous chunk left in the overlap
                     out[:, a:a + ov] = out[:, a:a + ov] * (1.0 - fade_in) + y[:, :ov] * fade_in
-                    out[:, a + ov:a + length] = y[:, ov:]
+                    out[:, a + ov:a + got] = y[:, ov:]
                 else:
-                    out[:, :length] = y
-                final = a + length - ov if a + length < n else n
+                    out[:, :got] = y
+                last = a + length >= n
+                if last:
+                    n_out = a + got
+                final = a + got - ov if not last else n_out
                 if on_chunk is not None and final > done:
                     on_chunk(done, out[:, done:final].copy())
                 done = max(done, final)
             i += len(grp)
-        return out
+        return out[:, :n_out]
 
-    def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None):
+    def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None,
+                       name_suffix=""):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
         ``infolder`` -> same file name in ``outfolder``), batched and pipelined: the lengths come from the WAV headers,
         the length-sorted list is cut into windows of 8 batches, and while window k is restored on the device (ragged
         batches of up to ``batch_size`` files, see restore_batch) a thread pool decodes / resamples / down-mixes window k+1 and encodes
-        window k-1 to PCM16.  Host memory holds two windows at most.  Returns the list of file names written."""
+        window k-1 to PCM16.  Host memory holds two windows at most.  ``mode`` 0 or 1 (restore_batch); ``name_suffix``
+        goes between base name and extension (the CLI's ``-mode<k>`` naming for ``--mode all``).  Returns the list of
+        file names written."""
         from concurrent.futures import ThreadPoolExecutor
         self._check_mode(mode)
-        if mode != 0:
-            raise NotImplementedError("restore_folder batches mode 0; use restore() per file for mode 1")
         files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] == ".wav")
         os.makedirs(outfolder, exist_ok=True)
         paths = [os.path.join(infolder, f) for f in files]
+        names = [("%s%s%s" % (os.path.splitext(f)[0], name_suffix, os.path.splitext(f)[1])) for f in files]
         with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
             # lengths from the headers only (cheap), so that the work list can be sorted and cut into windows before
             # anything is decoded; then a three-stage pipeline over the windows of the length-sorted list:
@@ -444,12 +483,12 @@ class VoiceFixer(nn.Module):
             for k, idx in enumerate(windows):
                 wavs = [f.result() for f in pending]
                 pending = [pool.submit(load, i) for i in windows[k + 1]] if k + 1 < len(windows) else []
-                outs = self.restore_batch(wavs, your_vocoder_func, batch_size)
+                outs = self.restore_batch(wavs, your_vocoder_func, batch_size, mode=mode)
                 for i, o in zip(idx, outs):
-                    writes.append(pool.submit(audio_io.save_wave, o, os.path.join(outfolder, files[i]), 44100))
+                    writes.append(pool.submit(audio_io.save_wave, o, os.path.join(outfolder, names[i]), 44100))
             for w in writes:
                 w.result()
-        return files
+        return names
 
     def restore(self, input, output, cuda=False, mode=0, your_vocoder_func=None):
         wav_10k = self._load_wav(input, sample_rate=44100)

@@ -2,13 +2,17 @@
 
 Mirrors voicefixer/tools/wav.py: ``save_wave`` (:9-37, int16 truncation) and the
 ``librosa.load(path, sr=44100)`` call of voicefixer/base.py:47-49.  librosa / soundfile are not
-available offline, so WAV files are read with scipy/stdlib and resampled with a polyphase
-filter (librosa would use soxr_hq: resampled inputs are NOT bit-identical to the reference's;
-44.1 kHz inputs are).  FLAC needs soundfile and is rejected loudly.
+available offline, so WAV files are read with scipy/stdlib, FLAC files (the format of the reference's own
+test fixtures, test/test.py:45-75) with the decoder / encoder of ``flac.py``, and other sample rates are resampled with a
+polyphase filter (librosa would use soxr_hq: resampled inputs are NOT bit-identical to the reference's;
+44.1 kHz inputs are).
 """
+import struct
+
 import numpy as np
 
 SR = 44100
+FORMATS = (".wav", ".flac")   # what ``save_wave`` can write (the reference asks soundfile.available_formats())
 
 
 def to_int16(frames):
@@ -22,24 +26,61 @@ def to_int16(frames):
 
 
 def save_wave(frames, fname, sample_rate=SR):
-    """(1, N) or (N,) float waveform -> PCM16 WAV (voicefixer/tools/wav.py:9-37)."""
+    """(1, N) or (N,) float waveform -> PCM16 WAV or FLAC by extension (voicefixer/tools/wav.py:9-37 writes through
+    soundfile, which picks the container from the extension the same way)."""
     frames = np.asarray(frames)
     if frames.ndim == 1:
         frames = frames[..., None]
     elif frames.ndim == 2 and frames.shape[0] < frames.shape[1] and frames.shape[0] <= 2:
         frames = frames.T  # (channels, N) -> (N, channels), as the reference's (1, N) output
     pcm = to_int16(frames)
-    if not str(fname).lower().endswith(".wav"):
-        raise RuntimeError("only .wav output is supported offline (the reference writes via soundfile): %s" % fname)
+    low = str(fname).lower()
+    if low.endswith(".flac"):
+        from . import flac
+        flac.write(fname, pcm, sample_rate, 16)
+        return
+    if not low.endswith(".wav"):
+        raise RuntimeError("output format not supported offline (WAV and FLAC are; the reference writes via "
+                           "soundfile): %s" % fname)
     from scipy.io import wavfile
     wavfile.write(fname, sample_rate, pcm if pcm.shape[1] > 1 else pcm[:, 0])
 
 
+def _riff_info(path):
+    """(sample_rate, frames) of a RIFF/WAVE file from its ``fmt `` and ``data`` chunk headers alone -- any bit depth
+    (scipy's memory-mapped read refuses 24-bit PCM, a very common studio format)."""
+    with open(path, "rb") as f:
+        head = f.read(12)
+        if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
+            raise RuntimeError("not a RIFF/WAVE file: %s" % path)
+        sr = block_align = None
+        while True:
+            ck = f.read(8)
+            if len(ck) < 8:
+                raise RuntimeError("WAV file without a data chunk: %s" % path)
+            cid, size = ck[:4], struct.unpack("<I", ck[4:])[0]
+            if cid == b"fmt ":
+                fmt = f.read(size + (size & 1))
+                _, _, sr, _, block_align, _ = struct.unpack("<HHIIHH", fmt[:16])
+            elif cid == b"data":
+                if not block_align:
+                    raise RuntimeError("WAV data chunk before the fmt chunk: %s" % path)
+                if size == 0xFFFFFFFF:      # streamed / RF64 file: fall back to what is really there
+                    pos = f.tell()
+                    f.seek(0, 2)
+                    size = f.tell() - pos
+                return int(sr), int(size // block_align)
+            else:
+                f.seek(size + (size & 1), 1)
+
+
 def wav_length(path, sample_rate=SR):
-    """Number of samples ``load_wav(path, sample_rate)`` will return, from the header alone (memory-mapped read)."""
-    from scipy.io import wavfile
-    sr, data = wavfile.read(path, mmap=True)
-    n = int(data.shape[0])
+    """Number of samples ``load_wav(path, sample_rate)`` will return, from the file header alone."""
+    if str(path).lower().endswith(".flac"):
+        from . import flac
+        sr, _, _, n = flac.info(path)
+    else:
+        sr, n = _riff_info(path)
     if sr == sample_rate:
         return n
     from math import gcd
@@ -50,18 +91,25 @@ def wav_length(path, sample_rate=SR):
 
 def load_wav(path, sample_rate=SR, mono=True):
     """Decode + (if needed) resample + downmix, float32 in [-1, 1] (librosa.load semantics)."""
-    if not str(path).lower().endswith(".wav"):
-        raise RuntimeError("only .wav input is supported offline (no libsndfile/FLAC decoder): %s" % path)
-    from scipy.io import wavfile
-    sr, data = wavfile.read(path)
-    if data.dtype == np.int16:
-        x = data.astype(np.float32) / 32768.0
-    elif data.dtype == np.int32:
-        x = data.astype(np.float32) / 2147483648.0
-    elif data.dtype == np.uint8:
-        x = (data.astype(np.float32) - 128.0) / 128.0
+    low = str(path).lower()
+    if low.endswith(".flac"):
+        from . import flac
+        sr, pcm, bps = flac.read(path)
+        x = pcm.astype(np.float32) / float(1 << (bps - 1))     # soundfile's float conversion
+        x = x[:, 0] if x.shape[1] == 1 else x
+    elif low.endswith(".wav"):
+        from scipy.io import wavfile
+        sr, data = wavfile.read(path)
+        if data.dtype == np.int16:
+            x = data.astype(np.float32) / 32768.0
+        elif data.dtype == np.int32:
+            x = data.astype(np.float32) / 2147483648.0      # (scipy delivers 24-bit PCM left-justified in int32)
+        elif data.dtype == np.uint8:
+            x = (data.astype(np.float32) - 128.0) / 128.0
+        else:
+            x = data.astype(np.float32)
     else:
-        x = data.astype(np.float32)
+        raise RuntimeError("input format not supported offline (WAV and FLAC are): %s" % path)
     if x.ndim == 2:
         x = x.mean(axis=1) if mono else x.T
     if sr != sample_rate:

@@ -30,6 +30,7 @@
 #include <mutex>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #ifndef VFX_X3_ABL
 #define VFX_X3_ABL 0  // development: ablations of the bf16x3 kernel only (1 = no LDS writes in the loop, 2 = no fragment reads / MFMA)
@@ -1173,7 +1174,13 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
     std::lock_guard<std::mutex> lock(mu);
     auto& e = pool[std::make_pair(dev, s)];
     if (e.second < bytes) {
-        if (e.first) (void)hipFree(e.first);  // (waits for the launches that still use it)
+        // A block that was handed out once is never freed or moved: a captured HIP graph (Pipeline.enable_graphs)
+        // bakes the workspace pointer of its capture stream into its kernel nodes, and torch recycles stream handles
+        // (round-robin pool of 32), so a later, larger request on the same handle must not invalidate that pointer.
+        // Outgrown blocks are retired, not released (split-K only serves launches of <= 192 workgroups: the blocks are
+        // a few MB, and their number is bounded by the distinct sizes a process asks for).
+        static std::vector<float*> retired;
+        if (e.first) retired.push_back(e.first);
         e.first = nullptr;
         e.second = 0;
         const size_t want = bytes + bytes / 2;

@@ -515,7 +515,8 @@ class Pipeline:
     def set_streams(self, streams):
         """Tell the engine how many HIP streams issue ``restore`` concurrently: the two-CU GRU keeps one workgroup
         per CU resident, so its launches are sized to 256 CUs / (4 workgroups per utterance x streams)."""
-        self.restorer.gru_group = max(1, min(ops.GRU2_MAX_B, 256 // (4 * max(1, int(streams)))))
+        self._n_streams = max(1, int(streams))
+        self.restorer.gru_group = max(1, min(ops.GRU2_MAX_B, 256 // (4 * self._n_streams)))
 
     def check(self):
         """Read the device-side error flags (ONE 4-byte D2H copy; call it where the result crosses to the host,
@@ -564,13 +565,17 @@ class Pipeline:
         with torch.cuda.graph(g, stream=s):
             static_out = self._restore_eager(static_in, N)
         torch.cuda.current_stream(dev).wait_stream(s)
-        return g, static_in, static_out
+        return [g, static_in, static_out, None]   # [3]: event recorded after the last user's clone of static_out
 
     def restore(self, wav, N, vocoder_func=None):
         """wav: device float32 (B, >=N).  Returns device (B, N)."""
         graphs = getattr(self, "_graphs", None)
+        # A graph entry owns ONE static input / output pair per (B, N) shape.  While several streams issue ``restore``
+        # concurrently (restore_batch / restore_folder: set_streams(> 1)) two of them could hold the same entry at once
+        # -- stream 1's copy into static_in is unordered against stream 0's replay -- so the replay path is bypassed
+        # there; sequential users on DIFFERENT streams are ordered through the entry's event.
         if graphs is not None and vocoder_func is None and ops.PROFILE is None and wav.shape[0] <= self._graph_cap[1] \
-                and N >= 1025:
+                and N >= 1025 and getattr(self, "_n_streams", 1) == 1:
             key = (wav.shape[0], N)
             ent = graphs.pop(key, None)
             if ent is None:
@@ -578,10 +583,17 @@ class Pipeline:
                     graphs.pop(next(iter(graphs)))
                 ent = self._capture(*key)
             graphs[key] = ent  # most recently used last
-            g, static_in, static_out = ent
+            g, static_in, static_out, last_use = ent
+            cur = torch.cuda.current_stream(self.device)
+            if last_use is not None:
+                cur.wait_event(last_use)   # the previous user (possibly on another stream) has finished with the pair
             static_in.copy_(wav[:, :N])
             g.replay()
-            return static_out.clone()
+            out = static_out.clone()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            ent[3] = ev
+            return out
         return self._restore_eager(wav, N, vocoder_func)
 
     def restore_rows(self, wav, lengths, force_ragged=False):
