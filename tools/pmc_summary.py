@@ -93,8 +93,32 @@ def mfma(m_csv, out):
     json.dump(doc, open(out, "w"), indent=1)
 
 
+def calib(fetch_csv, write_csv, out):
+    """tools/probe/fetch_calib.hip under the two PMC passes: counter bytes / known bytes per access width."""
+    known = float(1 << 30)
+    f, nf = read(fetch_csv)
+    w, nw = read(write_csv)
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        if "calib_" not in k:
+            continue
+        name = k.split("(")[0]
+        res[name] = {"known_bytes": int(known),
+                     "FETCH_SIZE_bytes": f[k]["FETCH_SIZE"] / nf[k] * 1024 if k in f else None,
+                     "WRITE_SIZE_bytes": w[k]["WRITE_SIZE"] / nw[k] * 1024 if k in w else None}
+        r = res[name]
+        r["fetch_over_known"] = round(r["FETCH_SIZE_bytes"] / known, 4) if r["FETCH_SIZE_bytes"] is not None else None
+        r["write_over_known"] = round(r["WRITE_SIZE_bytes"] / known, 4) if r["WRITE_SIZE_bytes"] is not None else None
+    json.dump({"note": "counter KB x 1024 / bytes the kernel is known to move (1 GiB, > the 256 MB Infinity Cache); "
+                       "read kernels should show fetch_over_known = 1 if the counter were exact",
+               "kernels": res}, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "hbm":
         hbm(*sys.argv[2:5])
+    elif sys.argv[1] == "calib":
+        calib(*sys.argv[2:5])
     else:
         mfma(*sys.argv[2:4])

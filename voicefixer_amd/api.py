@@ -299,20 +299,22 @@ class VoiceFixer(nn.Module):
             lo = break_point - SEG_LENGTH
             bounds.append((lo, min(break_point, n)))
             break_point += SEG_LENGTH
-        res = []
         full = [b for b in bounds if b[1] - b[0] == SEG_LENGTH]
         tail = [b for b in bounds if b[1] - b[0] != SEG_LENGTH]
-        for i in range(0, len(full), self.segment_batch):
-            grp = full[i:i + self.segment_batch]
-            seg = torch.from_numpy(np.stack([wav[a:b] for a, b in grp])).to(pipe.device)
-            out = self._restore_segments(pipe, seg, SEG_LENGTH, mode, your_vocoder_func)
-            res.extend(out[k:k + 1] for k in range(len(grp)))
-        for a, b in tail:
-            seg = torch.from_numpy(np.ascontiguousarray(wav[a:b]))[None].to(pipe.device)
-            res.append(self._restore_segments(pipe, seg, b - a, mode, your_vocoder_func))
-        out = torch.cat(res, -1).cpu().numpy()  # (synchronises)
-        pipe.check()
-        return out
+
+        def run():
+            res = []
+            for i in range(0, len(full), self.segment_batch):
+                grp = full[i:i + self.segment_batch]
+                seg = torch.from_numpy(np.stack([wav[a:b] for a, b in grp])).to(pipe.device)
+                out = self._restore_segments(pipe, seg, SEG_LENGTH, mode, your_vocoder_func)
+                res.extend(out[k:k + 1] for k in range(len(grp)))
+            for a, b in tail:
+                seg = torch.from_numpy(np.ascontiguousarray(wav[a:b]))[None].to(pipe.device)
+                res.append(self._restore_segments(pipe, seg, b - a, mode, your_vocoder_func))
+            return torch.cat(res, -1).cpu().numpy()  # (synchronises)
+
+        return pipe.run_checked(run)   # (device error flags are read here; a missed GRU hand-off re-runs the call)
 
     @staticmethod
     def _restore_segments(pipe, seg, n, mode, your_vocoder_func):
@@ -354,51 +356,62 @@ class VoiceFixer(nn.Module):
         main = torch.cuda.current_stream(pipe.device)
         for st in pool:
             st.wait_stream(main)
-        pending, staging = [], []
-        pipe.set_streams(len(pool))
-        try:
-            for nb, (kind, grp) in enumerate(plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio,
-                                                         ragged=your_vocoder_func is None)):
-                grp = [order[g] for g in grp]
-                with torch.cuda.stream(pool[nb % len(pool)]):
-                    if kind == "ragged":
-                        lens = [len(wavs[k]) for k in grp]
-                        # rows are padded in a PINNED staging buffer (torch caches pinned blocks) and uploaded without
-                        # blocking the host, so that the next batch is staged while this one's copy and kernels run
-                        host = torch.zeros((len(grp), max(lens)), dtype=torch.float32, pin_memory=True)
-                        hv = host.numpy()
-                        for r, k in enumerate(grp):
-                            hv[r, :lens[r]] = wavs[k]
-                        seg = host.to(pipe.device, non_blocking=True)
-                        staging.append(host)    # stays alive until the device has been synchronised below
-                        if mode == 1:
-                            cut = torch.zeros_like(seg)
-                            for r in range(len(grp)):          # the cut-off is a per-file quantity (base.py:87-104)
-                                y, _ = ops.hf_cut(seg[r:r + 1, :lens[r]], lens[r], 0.95)
-                                lens[r] = y.shape[1]
-                                cut[r, :lens[r]] = y[0]
-                            seg = cut[:, :max(lens)].contiguous()
-                        full = pipe.restore_rows(seg, lens)
-                        pending.append((grp, lens, full))
-                    else:
-                        n = len(wavs[grp[0]])
-                        parts = []
-                        for s0 in range(0, n, SEG_LENGTH):
-                            host = torch.from_numpy(np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH]
-                                                              for k in grp])).pin_memory()
-                            staging.append(host)
-                            parts.append(self._restore_segments(pipe, host.to(pipe.device, non_blocking=True),
-                                                                host.shape[1], mode, your_vocoder_func))
-                        full = torch.cat(parts, -1)
-                        pending.append((grp, [full.shape[-1]] * len(grp), full))
-        finally:
-            # whatever happened (a too-short file, an out-of-memory, a plugin vocoder error): drain the side streams
-            # before the staging buffers go away, give the GRU its single-stream launch size back, and read the
-            # device-side error flag HERE so that a later, unrelated call does not inherit it
-            torch.cuda.synchronize(pipe.device)
-            pipe.set_streams(1)
-            del staging
-        pipe.check()
+
+        def run():
+            pending, staging = [], []
+            pipe.set_streams(len(pool))
+            try:
+                for nb, (kind, grp) in enumerate(plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio,
+                                                             ragged=your_vocoder_func is None)):
+                    grp = [order[g] for g in grp]
+                    with torch.cuda.stream(pool[nb % len(pool)]):
+                        if kind == "ragged":
+                            lens = [len(wavs[k]) for k in grp]
+                            # rows are padded in a PINNED staging buffer (torch caches pinned blocks) and uploaded without
+                            # blocking the host, so that the next batch is staged while this one's copy and kernels run
+                            host = torch.zeros((len(grp), max(lens)), dtype=torch.float32, pin_memory=True)
+                            hv = host.numpy()
+                            for r, k in enumerate(grp):
+                                hv[r, :lens[r]] = wavs[k]
+                            seg = host.to(pipe.device, non_blocking=True)
+                            staging.append(host)    # stays alive until the device has been synchronised below
+                            if mode == 1:
+                                cut = torch.zeros_like(seg)
+                                for r in range(len(grp)):          # the cut-off is a per-file quantity (base.py:87-104)
+                                    y, _ = ops.hf_cut(seg[r:r + 1, :lens[r]], lens[r], 0.95)
+                                    lens[r] = y.shape[1]
+                                    cut[r, :lens[r]] = y[0]
+                                seg = cut[:, :max(lens)].contiguous()
+                            full = pipe.restore_rows(seg, lens)
+                            pending.append((grp, lens, full))
+                        else:
+                            n = len(wavs[grp[0]])
+                            parts = []
+                            for s0 in range(0, n, SEG_LENGTH):
+                                host = torch.from_numpy(np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH]
+                                                                  for k in grp])).pin_memory()
+                                staging.append(host)
+                                parts.append(self._restore_segments(pipe, host.to(pipe.device, non_blocking=True),
+                                                                    host.shape[1], mode, your_vocoder_func))
+                            full = torch.cat(parts, -1)
+                            pending.append((grp, [full.shape[-1]] * len(grp), full))
+            except BaseException:
+                # a batch raised (a too-short file, an out-of-memory, a plugin vocoder error): whatever the launches
+                # already queued leave in the device-side error flag belongs to THIS call -- drop it here so that a
+                # later, unrelated call does not inherit it
+                torch.cuda.synchronize(pipe.device)
+                if pipe.restorer.gru_err is not None:
+                    pipe.restorer.gru_err.zero_()
+                raise
+            finally:
+                # in every case: drain the side streams before the staging buffers go away and give the GRU its
+                # single-stream launch size back
+                torch.cuda.synchronize(pipe.device)
+                pipe.set_streams(1)
+                del staging
+            return pending
+
+        pending = pipe.run_checked(run)   # (reads the device error flags; a missed GRU hand-off re-runs the batches)
         for grp, lens, full in pending:
             full = full.cpu().numpy()
             for r, k in enumerate(grp):
@@ -434,8 +447,7 @@ class VoiceFixer(nn.Module):
             length = plan[i][1]
             grp = [c for c in plan[i:i + batch_size] if c[1] == length]
             seg = torch.from_numpy(np.stack([wav[a:a + length] for a, _ in grp])).to(pipe.device)
-            res = self._restore_segments(pipe, seg, length, mode, your_vocoder_func).cpu().numpy()
-            pipe.check()
+            res = pipe.run_checked(lambda: self._restore_segments(pipe, seg, length, mode, your_vocoder_func).cpu().numpy())
             got = res.shape[1]          # == length in mode 0; 512 * (length // 512) in mode 1
             for (a, _), y in zip(grp, res):
                 y = y[None]
