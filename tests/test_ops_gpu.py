@@ -1107,3 +1107,51 @@ def test_hf_cut_against_the_reference_executed_fixture():
     torch.cuda.synchronize()
     assert tuple(out.shape) == (1,) + g["hf_cut"].shape
     assert np.abs(out[0].cpu().numpy() - g["hf_cut"]).max() < 2e-5
+
+
+def _wino_adversarial_cases():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("winograd_error", os.path.join(os.path.dirname(GOLDEN), "..", "tools", "winograd_error.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("which", ["wg4", "wg"])
+def test_winograd_kernels_on_adversarial_operand_statistics(which):
+    """convwg4_kernel / convwg_kernel against a FLOAT64 convolution on the operand statistics of tools/winograd_error.py
+    --sweep (profiles/r03_winograd_error_sweep.txt): log-normal weight-norm row gains (sigma 1, 2), Student-t(2) entries,
+    smooth and second-difference filters, per-channel log-normal activation scales, a DC offset 30x the spread, slowly
+    varying inputs, 1e4 x outliers.  Bounds: the fp32 rounding the CPU restatement of the same arithmetic shows, x3 --
+    rms error / rms y per case, the worst output row's, and (where no outlier dominates a 6-tap window: F(4,3) mixes the
+    inputs of a quad, so its error is relative to the window's largest operand) max |error| / sum |w||x|."""
+    mod = _wino_adversarial_cases()
+    c, n, B = 256, 4096, 8
+    gen = torch.Generator().manual_seed(0)
+    # (rms_rel, worst_row_rms_rel, max_over_mag) bounds = 3x the sweep's F(4,3) column (F(2,3) is tighter; one bound for both)
+    for label, w, x in mod.cases(c, n, gen):
+        w, x = w.float(), x.float()
+        xin = x[:, : n + 2]                                    # y_dev[q] = sum_k w_k xin[q + k - 1]  (zero padding, dilation 1)
+        L = xin.shape[1]
+        ref = F.conv1d(xin.double()[None], w.double(), padding=1)[0]
+        mag = F.conv1d(xin.double().abs()[None], w.double().abs(), padding=1)[0]
+        lp = (L + 67) // 4 * 4
+        xd = torch.zeros((B, c, lp), device=DEV)
+        xd[:, :, :L] = xin.to(DEV)[None]
+        yd = torch.empty((B, c, lp), device=DEV)
+        wp = packing.pack_conv1d(w)
+        kw = {"wg4": packing.pack_wino4(wp).to(DEV)} if which == "wg4" else {"wg": packing.pack_wino(wp).to(DEV)}
+        ops.conv1d(xd, wp.to(DEV), torch.zeros(c, device=DEV), yd, L, 3, 1, 0, None, None, **kw)
+        torch.cuda.synchronize()
+        assert _lib.lib().vfx_last_conv_tile() % 100 == (80 if which == "wg4" else 70), "launch did not run on the Winograd kernel"
+        y = yd[3, :, :L].cpu().double()
+        assert torch.equal(yd[0, :, :L], yd[7, :, :L])         # identical rows: identical bits
+        err = y - ref
+        rms_rel = float(err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+        row_rel = float((err.pow(2).mean(1).sqrt() / ref.pow(2).mean(1).sqrt()).max())
+        over_mag = float((err.abs() / mag.clamp_min(1e-300)).max())
+        ill = "second-difference filters on slowly varying" in label     # |y| << sum |w||x|: every algorithm loses digits here
+        assert rms_rel < (3e-5 if ill else 3e-6), (label, rms_rel)
+        assert row_rel < (4e-5 if ill else 2e-5), (label, row_rel)
+        if "outliers" not in label:
+            assert over_mag < 3e-5, (label, over_mag)

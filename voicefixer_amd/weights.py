@@ -143,11 +143,15 @@ def _fill(shape, gen, std):
     return torch.randn(shape, generator=gen, dtype=torch.float32) * std
 
 
-def seeded_vocoder_state(seed=1234, legacy=False):
+def seeded_vocoder_state(seed=1234, legacy=False, gain_sigma=0.0):
     """Random-weight vocoder state dict with the exact key/shape set of the reference.
 
     Scales are chosen so activations stay O(1) through the 4 residual stacks and the
-    final tanh is not saturated (keeps the parity comparison meaningful)."""
+    final tanh is not saturated (keeps the parity comparison meaningful).
+    ``gain_sigma`` > 0: HEAVY-TAILED weight-norm gains -- every output row's ``g`` is multiplied by
+    exp(sigma z - sigma^2), z ~ N(0, 1): log-normal, mean square 1 (the layer's output energy is unchanged on average, so
+    the path stays in range), median exp(-sigma^2), rows up to ~exp(3 sigma - sigma^2) -- what trained weight-normed
+    checkpoints look like rather than the flat gains of the default (parity tests of round 3)."""
     gen = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     man = vocoder_manifest(legacy)
@@ -176,6 +180,8 @@ def seeded_vocoder_state(seed=1234, legacy=False):
             sd[k] = v
             norm = v.reshape(shape[0], -1).norm(dim=1).reshape(shape[0], 1, 1)
             jitter = 0.9 + 0.2 * torch.rand((shape[0], 1, 1), generator=gen)
+            if gain_sigma > 0:
+                jitter = jitter * torch.exp(gain_sigma * torch.randn((shape[0], 1, 1), generator=gen) - gain_sigma ** 2)
             sd[base + g_suffix] = norm * jitter
         elif k.endswith(".skip_conv.weight"):
             sd[k] = _fill(shape, gen, 1.0 / math.sqrt(shape[1]))
@@ -184,9 +190,11 @@ def seeded_vocoder_state(seed=1234, legacy=False):
     return sd
 
 
-def seeded_restorer_state(seed=4321):
+def seeded_restorer_state(seed=4321, gain_sigma=0.0):
     """Random-weight denoiser+UNet state dict (keys of restorer.model.Generator);
-    BN running stats are randomised so eval-BN is non-trivial."""
+    BN running stats are randomised so eval-BN is non-trivial.
+    ``gain_sigma`` > 0: the BatchNorm scales (the per-channel gains of this model) become log-normal with mean square 1,
+    exp(sigma z - sigma^2), as in ``seeded_vocoder_state``."""
     gen = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     man = restorer_manifest()
@@ -202,6 +210,8 @@ def seeded_restorer_state(seed=4321):
                 sd[k] = 0.75 + 0.5 * torch.rand(shape, generator=gen)
             elif leaf == "weight":
                 sd[k] = 0.8 + 0.4 * torch.rand(shape, generator=gen)
+                if gain_sigma > 0 and len(shape) == 1 and shape[0] > 1:   # (not the scalar BatchNorm2d(1) of the denoiser)
+                    sd[k] = sd[k] * torch.exp(gain_sigma * torch.randn(shape, generator=gen) - gain_sigma ** 2)
             else:
                 sd[k] = _fill(shape, gen, 0.1)
         elif ".gru." in k:
