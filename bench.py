@@ -426,6 +426,10 @@ def main():
         if code in (71, 72, 74):
             return ("wfusedw", bm, bl), "convw_kernel<%d,%d,*,*,3,*,2> (fused ResStack layer, Winograd second half)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, 2>" % (bm, bl)
+        if code == 88:
+            wgm = bm // 32
+            return ("wino4", bm, bl, 3, "s"), "convwg4s_kernel<%d,%d,*> (3x3 as Winograd F(4,3) along the map rows, kernel columns share one staged tile)" % (
+                wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+>" % (wgm, 4 // wgm)
         if code in (80, 89):
             wgm = bm // 32
             if code == 89:

@@ -124,7 +124,11 @@ uint64_t vfx_launch_count(void);
  *   code 16           conv_x3_kernel<BM,BL,...>                  (opt-in bf16x3 arithmetic)
  *   code 51 / 52 / 54 convw_kernel<BM,BL,*,*,NT=2|3,*,false>     (1-D, activation chunks of 8 / 16 / 32 channels)
  *   code 59           convw_kernel<BM,BL,*,*,NT=9,*,false>       (3x3 on a pitch map)
- *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels) */
+ *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels)
+ *   code 71 / 72 / 74 convw_kernel<BM,BL,*,*,3,*,2>              (vfx_resblock2_f32: second half as Winograd F(2,3))
+ *   code 70 / 79      convwg_kernel<..>                           (Winograd F(2,3): 1-D / 3x3 on a pitch map), BL = output positions
+ *   code 80 / 89      convwg4_kernel<..>                          (Winograd F(4,3): 1-D / 3x3 on a pitch map)
+ *   code 88           convwg4s_kernel<..>                         (Winograd F(4,3), 3x3 on a pitch map, kernel columns share one tile) */
 int vfx_last_conv_tile(void);
 
 /* ---- convolution family: implicit GEMM on v_mfma_f32_32x32x2_f32 -------------------

@@ -678,11 +678,17 @@ def test_conv2d_3x3_winograd(cfg):
 
 @pytest.mark.parametrize("cfg", [(32, 64, 64, 128, 6, True, False), (32, 32, 64, 128, 6, False, True), (32, 128, 128, 64, 5, True, True),
                                  (32, 384, 384, 128, 3, True, True), (32, 256, 128, 130, 4, True, False),
-                                 (48, 128, 64, 99, 5, True, True)])
+                                 (48, 128, 64, 99, 5, True, True),
+                                 # UNet level 0 (Cout = 32, pitch 128: the <1,4,8> instance), its 64 -> 32 decoder entry,
+                                 # a map height that is not a multiple of 4, Cin = 16 (one chunk pair)
+                                 (24, 32, 32, 64, 7, True, True), (24, 64, 32, 68, 7, True, False), (26, 16, 32, 63, 7, False, True),
+                                 (8, 64, 64, 256, 6, True, True), (40, 64, 128, 256, 3, True, False)])
 def test_conv2d_3x3_winograd4(cfg):
-    """3x3 on a pitch map on convwg4_kernel<.., NKX = 3> (vfx_act.w_wino4 = packing.pack_wino4_2d): Winograd F(4,3) along
-    the map rows, 18 products per four outputs instead of 36; same contract as test_conv2d_3x3_winograd (map heights that
-    are not multiples of 4 included)."""
+    """3x3 on a pitch map as Winograd F(4,3) along the map rows (vfx_act.w_wino4 = packing.pack_wino4_2d), 18 products per
+    four outputs instead of 36, on convwg4s_kernel: the three kernel columns read ONE staged tile at column shifts -1 / 0 /
+    +1, the pad columns of the map are the zero padding between rows (round 3).  Same contract as
+    test_conv2d_3x3_winograd: NaN in every guard band and pad column of the input, map heights that are not multiples of 4,
+    the in-place residual."""
     B, Cin, Cout, H, lp, affine, use_res = cfg
     P = 1 << lp
     x = _rand((B, Cin, H, P - 1), 311)
@@ -710,7 +716,7 @@ def test_conv2d_3x3_winograd4(cfg):
     ops.conv2d(xd, wp.to(DEV), bias.to(DEV), yd, H, lp, 3, act, rd, wg4=wg4)
     torch.cuda.synchronize()
     assert _lib.lib().vfx_launch_count() == before + 1
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 89, "launch did not run on convwg4_kernel (3x3)"
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 88, "launch did not run on convwg4s_kernel (3x3, shared staging)"
     got = _from_pitch(yd, H, lp)
     _close(got[..., : P - 1], ref, 2e-5)
     assert (got[..., P - 1] == 0).all()  # pad column written as zero
@@ -719,6 +725,33 @@ def test_conv2d_3x3_winograd4(cfg):
         ops.conv2d(xd, wp.to(DEV), bias.to(DEV), rd2, H, lp, 3, act, rd2, wg4=wg4)
         torch.cuda.synchronize()
         _close(_from_pitch(rd2, H, lp)[..., : P - 1], ref, 2e-5)
+
+
+def test_conv2d_3x3_winograd4_ragged_rows():
+    """Per-row map heights (ragged batches: row b of the batch is a map of rows[b] / P <= H rows): every row equals the
+    convolution of that map alone (zero padding below ITS last row), nothing is written past it."""
+    B, Cin, Cout, H, lp = 12, 64, 64, 128, 6
+    P = 1 << lp
+    heights = [128, 64, 127, 4, 65, 128, 1, 96, 33, 128, 2, 100]
+    x = _rand((B, Cin, H, P - 1), 411)
+    w = _rand((Cout, Cin, 3, 3), 412, (Cin * 9) ** -0.5)
+    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(413))
+    shift = _rand((Cin,), 414, 0.3)
+    xd = ops.guarded(B, Cin, H * P, P + 1 + 264, DEV)
+    xd._vfx_base.fill_(float("nan"))
+    xd[:, :, :H * P] = _to_pitch(x, lp).to(DEV)
+    ops.with_rows(xd, torch.tensor([h * P for h in heights], dtype=torch.int32, device=DEV))
+    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
+    act = ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=scale.to(DEV), shift=shift.to(DEV))
+    wp = packing.pack_conv2d(w)
+    ops.conv2d(xd, wp.to(DEV), None, yd, H, lp, 3, act, None, wg4=packing.pack_wino4_2d(wp).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 88
+    got = _from_pitch(yd, H, lp)
+    for b, h in enumerate(heights):
+        ref = F.conv2d(_ref_act(x[b:b + 1, :, :h], _lib.PRE_AFFINE_LRELU, 0.01, scale, shift), w, padding=1)
+        _close(got[b:b + 1, :, :h, : P - 1], ref, 2e-5)
+        assert torch.isnan(got[b, :, h:]).all()
 
 
 @pytest.mark.parametrize("cfg", [(2, 32, 32, 64, 7, True, True), (1, 64, 64, 48, 6, True, False),

@@ -1196,6 +1196,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 
 #include "vfx_convw.inc"
 #include "vfx_convwg.inc"
+#include "vfx_convwg2d.inc"
 
 template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS = 1>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
@@ -1404,7 +1405,8 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
             const int P = in_mask + 1;
             bool ok = true;
             for (int t = 0; t < 9; ++t) ok &= phs[0].taps[t].off == (t / 3 - 1) * P + (t % 3 - 1) && phs[0].taps[t].slab == t;
-            if (ok) rc4 = try_launch_convwg4_2d(a, x, P, act->w_wino4, stream);
+            if (ok) rc4 = try_launch_convwg4s_2d(a, x, P, act->w_wino4, stream);
+            if (ok && rc4 == VFX_ENOTSUP) rc4 = try_launch_convwg4_2d(a, x, P, act->w_wino4, stream);
         } else {
             rc4 = try_launch_convwg4(a, x, nphase, phs, act->w_wino4, stream);
         }

@@ -211,7 +211,7 @@ extern "C" void vfx_gru_layout(int* kreg, int* klds, int* kstr) {
 
 // ======================================================================================
 // Two-CU variant: each (utterance, direction) sequence is owned by a PAIR of workgroups.
-// Workgroup r holds the k-half r of W_hh^T entirely in registers (64 k x 3 gate rows per thread,
+// Workgroup r holds the k-half r of W_hh^T entirely in registers (192 weights per thread,
 // 512 threads) -- nothing is streamed from L2 any more, which is what bounds the one-workgroup
 // kernel (384 KB per step at the per-CU L2 rate).  Per step each workgroup computes the partial
 // gate pre-activations over its k-half for all 768 rows, keeps the 384 that belong to "its" hidden
@@ -229,39 +229,57 @@ extern "C" void vfx_gru_layout(int* kreg, int* klds, int* kstr) {
 typedef unsigned long long u64;
 #define G2_SPIN_LIMIT (1u << 24)
 
+// Thread map (round 3): thread t = (unit index ju = t >> 2 of a 128-unit half, k-quarter kq = t & 3).  Every thread
+// holds 2 x 3 x 32 weights: its 32 k-rows of the three gate rows of the PARTNER's unit ju and of its OWN unit ju.  A time
+// step runs the partner's rows FIRST (96 FMAs, the four k-quarters of a unit are neighbouring lanes: two DPP quad
+// permutes add them, no LDS, no barrier) and sends them off, THEN its own rows -- so the 0.8-1.0 us a granule needs to
+// reach the other CU overlaps the second half of the arithmetic instead of following all of it.  One barrier per step
+// (the new h); round 2 had thread (row j, k-half), one block of 192 FMAs, an LDS exchange between the k-halves and two
+// barriers, and sent after everything was summed: 2.2 us per step.
+__device__ __forceinline__ float quad_sum(float v) {
+    // sum over the four lanes of a quad: quad_perm [1,0,3,2] then [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+    return v;
+}
+
 __global__ __launch_bounds__(512, 2) void gru2_kernel(const float* __restrict__ gi, const float* __restrict__ whh_t,
                                                       const float* __restrict__ bhh, float* __restrict__ out,
                                                       long long o_bs, long long o_cs, int Tpitch, u64* __restrict__ mbox,
                                                       int* __restrict__ err, const int* __restrict__ t_rows) {
-    __shared__ float hloc[2][128];
-    __shared__ float part[3][256];
+    __shared__ __attribute__((aligned(16))) float hloc[2][128];
     const int tid = threadIdx.x;
-    const int j = tid & 255, kq = tid >> 8;
+    const int ju = tid >> 2, kq = tid & 3;
     const int wg = blockIdx.x;
     const int r = wg & 1, pair = wg >> 1;
     const int dir = pair & 1, b = pair >> 1;
     const int T = t_rows ? t_rows[b] : Tpitch;   // ragged batches: frames of this sequence (both partners read the same value)
-    const float* W = whh_t + (long long)dir * GRU_H * GRU_G + (long long)(r * 128 + kq * 64) * GRU_G;
+    // k-rows of this thread: hidden units 128 r + 32 kq .. + 31 (this workgroup's own h values)
+    const float* W = whh_t + (long long)dir * GRU_H * GRU_G + (long long)(r * 128 + kq * 32) * GRU_G;
     const float* g = gi + (long long)b * Tpitch * (2 * GRU_G) + dir * GRU_G;
-    const bool mine = (j >> 7) == r;       // unit j is finalised by this workgroup
-    const int ju = j & 127;
-    float* o = out + (long long)b * o_bs + (long long)(dir * GRU_H + j) * o_cs;
+    const int own = r * 128 + ju, peer = (r ^ 1) * 128 + ju;   // hidden units whose gate rows this thread works on
+    const bool lead = kq == 0;             // the lane of a quad that sends / receives / finalises unit ju
+    float* o = out + (long long)b * o_bs + (long long)(dir * GRU_H + own) * o_cs;
     // mailbox of workgroup (pair, r): [slot 2][384] granules, written by the partner
     u64* my_box = mbox + ((long long)pair * 2 + r) * 2 * 384;
     u64* peer_box = mbox + ((long long)pair * 2 + (r ^ 1)) * 2 * 384;
 
-    float wr[64], wz[64], wn[64];
+    float wpr[32], wpz[32], wpn[32];       // partner's unit: rows peer, 256 + peer, 512 + peer
+    float wor[32], woz[32], won[32];       // own unit
 #pragma unroll
-    for (int k = 0; k < 64; ++k) {
-        wr[k] = W[k * GRU_G + j];
-        wz[k] = W[k * GRU_G + GRU_H + j];
-        wn[k] = W[k * GRU_G + 2 * GRU_H + j];
+    for (int k = 0; k < 32; ++k) {
+        wpr[k] = W[k * GRU_G + peer];
+        wpz[k] = W[k * GRU_G + GRU_H + peer];
+        wpn[k] = W[k * GRU_G + 2 * GRU_H + peer];
+        wor[k] = W[k * GRU_G + own];
+        woz[k] = W[k * GRU_G + GRU_H + own];
+        won[k] = W[k * GRU_G + 2 * GRU_H + own];
     }
     float br = 0.f, bz = 0.f, bn = 0.f, hj = 0.f;
-    if (kq == 0 && mine) {
-        br = bhh[dir * GRU_G + j];
-        bz = bhh[dir * GRU_G + GRU_H + j];
-        bn = bhh[dir * GRU_G + 2 * GRU_H + j];
+    if (lead) {
+        br = bhh[dir * GRU_G + own];
+        bz = bhh[dir * GRU_G + GRU_H + own];
+        bn = bhh[dir * GRU_G + 2 * GRU_H + own];
     }
     if (tid < 256) hloc[tid >> 7][tid & 127] = 0.f;
     __syncthreads();
@@ -269,82 +287,83 @@ __global__ __launch_bounds__(512, 2) void gru2_kernel(const float* __restrict__ 
     int t = dir ? T - 1 : 0;
     const int dt = dir ? -1 : 1;
     float gr = 0.f, gz = 0.f, gn = 0.f;
-    if (kq == 0 && mine) {
-        gr = g[(long long)t * (2 * GRU_G) + j];
-        gz = g[(long long)t * (2 * GRU_G) + GRU_H + j];
-        gn = g[(long long)t * (2 * GRU_G) + 2 * GRU_H + j];
+    if (lead) {
+        gr = g[(long long)t * (2 * GRU_G) + own];
+        gz = g[(long long)t * (2 * GRU_G) + GRU_H + own];
+        gn = g[(long long)t * (2 * GRU_G) + 2 * GRU_H + own];
     }
     bool failed = false;
 
     for (int s = 0; s < T; ++s) {
-        const float* h = hloc[s & 1] + kq * 64;
+        const float* h = hloc[s & 1] + kq * 32;
         const int tn = t + dt;
         float ngr = 0.f, ngz = 0.f, ngn = 0.f;
-        if (kq == 0 && mine && s + 1 < T) {
-            ngr = g[(long long)tn * (2 * GRU_G) + j];
-            ngz = g[(long long)tn * (2 * GRU_G) + GRU_H + j];
-            ngn = g[(long long)tn * (2 * GRU_G) + 2 * GRU_H + j];
+        if (lead && s + 1 < T) {           // next step's x-projection
+            ngr = g[(long long)tn * (2 * GRU_G) + own];
+            ngz = g[(long long)tn * (2 * GRU_G) + GRU_H + own];
+            ngn = g[(long long)tn * (2 * GRU_G) + 2 * GRU_H + own];
         }
+        // ---- partner's rows first (h is read from LDS four values at a time, again in the second half: keeping all 32
+        // in registers across both halves does not fit next to the 192 weights)
         float ar = 0.f, az = 0.f, an = 0.f;
 #pragma unroll
-        for (int k = 0; k < 64; k += 4) {
-            const float4 hv = *reinterpret_cast<const float4*>(h + k);
-            ar = fmaf(wr[k], hv.x, ar); az = fmaf(wz[k], hv.x, az); an = fmaf(wn[k], hv.x, an);
-            ar = fmaf(wr[k + 1], hv.y, ar); az = fmaf(wz[k + 1], hv.y, az); an = fmaf(wn[k + 1], hv.y, an);
-            ar = fmaf(wr[k + 2], hv.z, ar); az = fmaf(wz[k + 2], hv.z, az); an = fmaf(wn[k + 2], hv.z, an);
-            ar = fmaf(wr[k + 3], hv.w, ar); az = fmaf(wz[k + 3], hv.w, az); an = fmaf(wn[k + 3], hv.w, an);
-            if ((k & 15) == 12) __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < 8; ++k) {
+            const float4 hv = *reinterpret_cast<const float4*>(h + 4 * k);
+            ar = fmaf(wpr[4 * k], hv.x, ar); az = fmaf(wpz[4 * k], hv.x, az); an = fmaf(wpn[4 * k], hv.x, an);
+            ar = fmaf(wpr[4 * k + 1], hv.y, ar); az = fmaf(wpz[4 * k + 1], hv.y, az); an = fmaf(wpn[4 * k + 1], hv.y, an);
+            ar = fmaf(wpr[4 * k + 2], hv.z, ar); az = fmaf(wpz[4 * k + 2], hv.z, az); an = fmaf(wpn[4 * k + 2], hv.z, an);
+            ar = fmaf(wpr[4 * k + 3], hv.w, ar); az = fmaf(wpz[4 * k + 3], hv.w, az); an = fmaf(wpn[4 * k + 3], hv.w, an);
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);  // bound how far the h reads are hoisted
         }
-        if (kq == 1) {
-            part[0][j] = ar;
-            part[1][j] = az;
-            part[2][j] = an;
+        ar = quad_sum(ar); az = quad_sum(az); an = quad_sum(an);
+        const unsigned tag = (unsigned)(s + 1);
+        const int slot = (s & 1) * 384;
+        if (lead) {
+            // hand the partials of the partner's unit over: one 8-byte agent-scope store per value (the data is the flag)
+            u64* dst = peer_box + slot + ju * 3;
+            __hip_atomic_store(dst + 0, ((u64)tag << 32) | __float_as_uint(ar), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 1, ((u64)tag << 32) | __float_as_uint(az), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(dst + 2, ((u64)tag << 32) | __float_as_uint(an), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        __syncthreads();
-        if (kq == 0) {
-            ar += part[0][j];
-            az += part[1][j];
-            an += part[2][j];
-            const unsigned tag = (unsigned)(s + 1);
-            const int slot = (s & 1) * 384;
-            if (!mine) {
-                // hand the partials of the partner's units over: one 8-byte sc1 store per value
-                u64* dst = peer_box + slot + ju * 3;
-                __hip_atomic_store(dst + 0, ((u64)tag << 32) | __float_as_uint(ar), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 1, ((u64)tag << 32) | __float_as_uint(az), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(dst + 2, ((u64)tag << 32) | __float_as_uint(an), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                const u64* src = my_box + slot + ju * 3;
-                float pv[3];
-                // the three granules are polled TOGETHER: three loads in flight per round trip to L2 instead of three
-                // dependent round trips (one per gate) -- the hand-off is the critical path of every time step
-                u64 v0 = 0, v1 = 0, v2 = 0;
-                unsigned spins = 0;
-                for (;;) {
-                    v0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    v2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag && (unsigned)(v2 >> 32) == tag) break;
-                    if (++spins > G2_SPIN_LIMIT) { failed = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                pv[0] = __uint_as_float((unsigned)v0);
-                pv[1] = __uint_as_float((unsigned)v1);
-                pv[2] = __uint_as_float((unsigned)v2);
-                ar += pv[0] + br;
-                az += pv[1] + bz;
-                an += pv[2] + bn;
-                const float rr = 1.f / (1.f + expf(-(gr + ar)));
-                const float zz = 1.f / (1.f + expf(-(gz + az)));
-                const float nn = tanhf(gn + rr * an);
-                hj = (1.f - zz) * nn + zz * hj;
-                hloc[(s + 1) & 1][ju] = hj;
-                o[t] = hj;
-                gr = ngr; gz = ngz; gn = ngn;
+        __builtin_amdgcn_sched_barrier(0);   // (keep the send in front of the second half)
+        // ---- own rows, while the granules travel
+        float cr = 0.f, cz = 0.f, cn = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float4 hv = *reinterpret_cast<const float4*>(h + 4 * k);
+            cr = fmaf(wor[4 * k], hv.x, cr); cz = fmaf(woz[4 * k], hv.x, cz); cn = fmaf(won[4 * k], hv.x, cn);
+            cr = fmaf(wor[4 * k + 1], hv.y, cr); cz = fmaf(woz[4 * k + 1], hv.y, cz); cn = fmaf(won[4 * k + 1], hv.y, cn);
+            cr = fmaf(wor[4 * k + 2], hv.z, cr); cz = fmaf(woz[4 * k + 2], hv.z, cz); cn = fmaf(won[4 * k + 2], hv.z, cn);
+            cr = fmaf(wor[4 * k + 3], hv.w, cr); cz = fmaf(woz[4 * k + 3], hv.w, cz); cn = fmaf(won[4 * k + 3], hv.w, cn);
+            if (k & 1) __builtin_amdgcn_sched_barrier(0);
+        }
+        cr = quad_sum(cr); cz = quad_sum(cz); cn = quad_sum(cn);
+        if (lead) {
+            const u64* src = my_box + slot + ju * 3;
+            // the three granules are polled TOGETHER: three loads in flight per round trip instead of three dependent ones
+            u64 v0 = 0, v1 = 0, v2 = 0;
+            unsigned spins = 0;
+            for (;;) {
+                v0 = __hip_atomic_load(src + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                v2 = __hip_atomic_load(src + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((unsigned)(v0 >> 32) == tag && (unsigned)(v1 >> 32) == tag && (unsigned)(v2 >> 32) == tag) break;
+                if (++spins > G2_SPIN_LIMIT) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
             }
+            cr += __uint_as_float((unsigned)v0) + br;
+            cz += __uint_as_float((unsigned)v1) + bz;
+            cn += __uint_as_float((unsigned)v2) + bn;
+            const float rr = 1.f / (1.f + expf(-(gr + cr)));
+            const float zz = 1.f / (1.f + expf(-(gz + cz)));
+            const float nn = tanhf(gn + rr * cn);
+            hj = (1.f - zz) * nn + zz * hj;
+            hloc[(s + 1) & 1][ju] = hj;
+            o[t] = hj;
+            gr = ngr; gz = ngz; gn = ngn;
         }
         t = tn;
-        if (__syncthreads_or(failed ? 1 : 0)) break;  // barrier + uniform exit if any lane timed out
+        if (__syncthreads_or(failed ? 1 : 0)) break;  // barrier (the new h is visible) + uniform exit if any lane timed out
     }
     if (failed) atomicExch(err, 1);
 }

@@ -268,9 +268,11 @@ class _ConvBlock:
         self.w1g = _dev(packing.pack_wino2d(wp1), device) if wino and self.cin % cin_step == 0 else None
         self.w2g = _dev(packing.pack_wino2d(wp2), device) if wino and self.cout % cin_step == 0 else None
         # ... and F(4,3) (convwg4_kernel, NKX = 3) for the wide instances
-        wino4 = WINO2D and WINO4_2D and self.cout % 64 == 0
-        self.w1g4 = _dev(packing.pack_wino4_2d(wp1), device) if wino4 and self.cin % 32 == 0 else None
-        self.w2g4 = _dev(packing.pack_wino4_2d(wp2), device) if wino4 else None
+        # (convwg4s_kernel: 64-channel blocks with Cin % 32 == 0, or Cout = 32 -- UNet level 0 -- with Cin % 16 == 0)
+        wino4 = WINO2D and WINO4_2D and self.cout % 32 == 0
+        cin_step4 = 32 if self.cout % 64 == 0 else 16
+        self.w1g4 = _dev(packing.pack_wino4_2d(wp1), device) if wino4 and self.cin % cin_step4 == 0 else None
+        self.w2g4 = _dev(packing.pack_wino4_2d(wp2), device) if wino4 and self.cout % cin_step4 == 0 else None
         self.act1 = ops.Act(pre=PRE_AFFINE_LRELU, pre_slope=0.01, scale=_dev(s1, device), shift=_dev(sh1, device),
                             post=POST_LRELU, post_slope=0.01)
         self.shortcut = None
