@@ -430,20 +430,14 @@ def main():
             wgm = bm // 32
             return ("wino4", bm, bl, 3, "s"), "convwg4s_kernel<%d,%d,*> (3x3 as Winograd F(4,3) along the map rows, kernel columns share one staged tile)" % (
                 wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+>" % (wgm, 4 // wgm)
-        if code in (80, 89):
+        if code == 80:
             wgm = bm // 32
-            if code == 89:
-                return ("wino4", bm, bl, 3), "convwg4_kernel<%d,%d,3> (3x3 as Winograd F(4,3) along the map rows)" % (
-                    wgm, 4 // wgm), r"convwg4_kernel<%d, %d, 3>" % (wgm, 4 // wgm)
-            return ("wino4", bm, bl), "convwg4_kernel<%d,%d,1> (Winograd F(4,3), %d ch x %d output quads)" % (
-                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, 1>" % (wgm, 4 // wgm)
-        if code in (70, 79):
+            return ("wino4", bm, bl), "convwg4_kernel<%d,%d> (Winograd F(4,3), %d ch x %d output quads)" % (
+                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d>" % (wgm, 4 // wgm)
+        if code == 70:
             wgm = bm // 32
-            if code == 79:
-                return ("wino2d", bm, bl), "convwg_kernel<%d,%d,3> (3x3 as Winograd F(2,3) along the map rows)" % (
-                    wgm, 4 // wgm), r"convwg_kernel<%d, %d, 3, \d+>" % (wgm, 4 // wgm)
-            return ("wino", bm, bl), "convwg_kernel<%d,%d,1> (Winograd F(2,3), %d ch x %d output pairs)" % (
-                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d, 1, \d+>" % (wgm, 4 // wgm)
+            return ("wino", bm, bl), "convwg_kernel<%d,%d> (Winograd F(2,3), %d ch x %d output pairs)" % (
+                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d>" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
@@ -457,7 +451,7 @@ def main():
             return 0.5         # six products per four outputs; the direct sum has twelve
         if key[0] == "wfusedw":
             return 5.0 / 6.0   # the dilated half direct (3 products per output), the dilation-1 half Winograd (2)
-        return 2.0 / 3.0 if key[0] in ("wino", "wino2d") else 1.0
+        return 2.0 / 3.0 if key[0] == "wino" else 1.0
 
     by_fam = {}
     stft_bytes, stft_secs, stft_n = 0, 0.0, 0

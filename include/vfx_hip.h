@@ -95,13 +95,16 @@ typedef struct {
                                like w_direct with 4 slabs (packing.py::pack_wino).  Large launches with Cin % 32 == 0,
                                Cout % 128 == 0, zero padding and no BatchNorm pre-activation then run on convwg_kernel:
                                two outputs a dilation apart share four products instead of six (1.5x fewer fp32 MFMAs;
-                               the result differs from the direct sum by fp32 rounding only).  For vfx_conv2d_f32 with
-                               ksize 3: the transform along the kernel's row axis for each kernel column, 12 slabs
-                               kx*4 + plane (packing.py::pack_wino2d); Cout % 64 == 0, Cin % 32 == 0, a guard band. */
-    const float* w_wino4;   /* optional (may be NULL), k = 3 stride-1 Conv1d only: the Winograd F(4,3) transform, six
+                               the result differs from the direct sum by fp32 rounding only).  Ignored by
+                               vfx_conv2d_f32 (its 3x3 launches take w_wino4). */
+    const float* w_wino4;   /* optional (may be NULL), k = 3 stride-1 Conv1d: the Winograd F(4,3) transform, six
                                slabs U = G w (packing.py::pack_wino4): four outputs a dilation apart share six products
                                (2x fewer fp32 MFMAs than the direct sum; rounding error ~3x that of the direct sum, ~1e-6
-                               relative).  Tried before w_wino; same shape conditions. */
+                               relative).  Tried before w_wino; same shape conditions.  For vfx_conv2d_f32 with ksize 3:
+                               the transform along the kernel's ROW axis for each kernel column, 18 slabs kx*6 + plane
+                               (packing.py::pack_wino4_2d); launches with Cout % 64 == 0 and Cin % 32 == 0, or Cout % 32
+                               == 0 and Cin % 16 == 0, on maps of pitch <= 64 / 128 run on convwg4s_kernel (four
+                               vertically adjacent outputs share 18 products instead of 36). */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0

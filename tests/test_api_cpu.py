@@ -192,9 +192,9 @@ def _unpack_direct(wd):
 
 
 def test_pack_wino_is_the_f23_weight_transform():
-    """packing.pack_wino / pack_wino2d (vfx_act.w_wino): with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the inputs
+    """packing.pack_wino (vfx_act.w_wino): with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the inputs
     x[q-d], x[q], x[q+d], x[q+2d] and m_k = U_k V_k, the pair (m0+m1+m2, m1-m2-m3) must be the direct k = 3 convolution
-    at q and q + d -- evaluated here in float64 on the CPU from the PACKED weights, for the 1-D and the 3x3 layout."""
+    at q and q + d -- evaluated here in float64 on the CPU from the PACKED weights."""
     import torch.nn.functional as F
     from voicefixer_amd import packing
     g = torch.Generator().manual_seed(5)
@@ -210,21 +210,6 @@ def test_pack_wino_is_the_f23_weight_transform():
         m = [U[k].t() @ V[k] for k in range(4)]
         assert torch.allclose(m[0] + m[1] + m[2], ref[:, q], atol=1e-5)
         assert torch.allclose(m[1] - m[2] - m[3], ref[:, q + d], atol=1e-5)
-    # 3x3: the transform runs along the kernel ROW axis for every kernel column kx (slab kx*4 + plane)
-    w2 = torch.randn((cout, cin, 3, 3), generator=g)
-    x2 = torch.randn((1, cin, 6, 7), generator=g)
-    ref2 = F.conv2d(x2.double(), w2.double(), padding=1)[0]
-    U2 = _unpack_direct(packing.pack_wino2d(packing.pack_conv2d(w2))).double()       # [12][Cin][Cout]
-    xp2 = F.pad(x2.double()[0], (1, 1, 1, 2))
-    for (h, xx) in ((0, 0), (2, 3), (4, 6)):
-        m = [torch.zeros(cout, dtype=torch.float64) for _ in range(4)]
-        for kx in range(3):
-            dd = [xp2[:, h + k, xx + kx] for k in range(4)]                          # rows h-1 .. h+2 at column xx+kx-1
-            V = [dd[0] - dd[2], dd[1] + dd[2], dd[2] - dd[1], dd[1] - dd[3]]
-            for k in range(4):
-                m[k] = m[k] + U2[kx * 4 + k].t() @ V[k]
-        assert torch.allclose(m[0] + m[1] + m[2], ref2[:, h, xx], atol=1e-5)
-        assert torch.allclose(m[1] - m[2] - m[3], ref2[:, h + 1, xx], atol=1e-5)
 
 
 def test_pack_wino4_is_the_f43_weight_transform():

@@ -629,54 +629,6 @@ def test_conv2d_3x3_convw(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(32, 64, 64, 128, 6, True, False), (32, 32, 64, 128, 6, False, True), (32, 128, 128, 64, 5, True, True),
-                                 (32, 64, 128, 64, 5, False, True), (32, 384, 384, 128, 3, True, True),
-                                 (32, 256, 128, 130, 4, True, False), (48, 128, 64, 99, 5, True, True),
-                                 (32, 32, 32, 256, 7, True, True), (32, 64, 32, 64, 7, False, False),   # Cout = 32: 32 ch x 256 pairs
-                                 (32, 16, 32, 129, 6, True, False)])
-def test_conv2d_3x3_winograd(cfg):
-    """3x3 on a pitch map on convwg_kernel<.., NKX = 3> (vfx_act.w_wino = packing.pack_wino2d): Winograd F(2,3) along
-    the map rows, 12 products per output pair instead of 18.  Same contract as the direct kernels: eval-BatchNorm
-    pre-activation or none, residual (also in place), NaN in the input's pad column and guard band, pad column written
-    as zero; odd map heights (the last pair has one row)."""
-    B, Cin, Cout, H, lp, affine, use_res = cfg
-    P = 1 << lp
-    x = _rand((B, Cin, H, P - 1), 211)
-    w = _rand((Cout, Cin, 3, 3), 212, (Cin * 9) ** -0.5)
-    scale = 0.8 + 0.4 * torch.rand(Cin, generator=torch.Generator().manual_seed(213))
-    shift = _rand((Cin,), 214, 0.3)
-    bias = _rand((Cout,), 216, 0.1)
-    res = _rand((B, Cout, H, P - 1), 215) if use_res else None
-    xin = _ref_act(x, _lib.PRE_AFFINE_LRELU, 0.01, scale, shift) if affine else x
-    ref = F.conv2d(xin, w, bias, padding=1)
-    if use_res:
-        ref = ref + res
-    ref = F.leaky_relu(ref, 0.01) if affine else ref
-    G = P + 1 + 264
-    xd = ops.guarded(B, Cin, H * P, G, DEV)
-    xd._vfx_base.fill_(float("nan"))
-    xd[:, :, :H * P] = _to_pitch(x, lp).to(DEV)
-    yd = torch.full((B, Cout, H * P), float("nan"), device=DEV)
-    rd = torch.nan_to_num(_to_pitch(res, lp).to(DEV), nan=0.0) if use_res else None
-    act = (ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=scale.to(DEV), shift=shift.to(DEV),
-                   post=_lib.POST_LRELU, post_slope=0.01) if affine else None)
-    wp = packing.pack_conv2d(w)
-    wg = packing.pack_wino2d(wp).to(DEV)
-    before = _lib.lib().vfx_launch_count()
-    ops.conv2d(xd, wp.to(DEV), bias.to(DEV), yd, H, lp, 3, act, rd, wg=wg)
-    torch.cuda.synchronize()
-    assert _lib.lib().vfx_launch_count() == before + 1
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 79, "launch did not run on convwg_kernel (3x3)"
-    got = _from_pitch(yd, H, lp)
-    _close(got[..., : P - 1], ref, 2e-5)
-    assert (got[..., P - 1] == 0).all()  # pad column written as zero
-    if use_res:  # in-place residual (the engine's ConvBlockRes pattern: out aliases the residual)
-        rd2 = rd.clone()
-        ops.conv2d(xd, wp.to(DEV), bias.to(DEV), rd2, H, lp, 3, act, rd2, wg=wg)
-        torch.cuda.synchronize()
-        _close(_from_pitch(rd2, H, lp)[..., : P - 1], ref, 2e-5)
-
-
-@pytest.mark.parametrize("cfg", [(32, 64, 64, 128, 6, True, False), (32, 32, 64, 128, 6, False, True), (32, 128, 128, 64, 5, True, True),
                                  (32, 384, 384, 128, 3, True, True), (32, 256, 128, 130, 4, True, False),
                                  (48, 128, 64, 99, 5, True, True),
                                  # UNet level 0 (Cout = 32, pitch 128: the <1,4,8> instance), its 64 -> 32 decoder entry,
@@ -686,9 +638,9 @@ def test_conv2d_3x3_winograd(cfg):
 def test_conv2d_3x3_winograd4(cfg):
     """3x3 on a pitch map as Winograd F(4,3) along the map rows (vfx_act.w_wino4 = packing.pack_wino4_2d), 18 products per
     four outputs instead of 36, on convwg4s_kernel: the three kernel columns read ONE staged tile at column shifts -1 / 0 /
-    +1, the pad columns of the map are the zero padding between rows (round 3).  Same contract as
-    test_conv2d_3x3_winograd: NaN in every guard band and pad column of the input, map heights that are not multiples of 4,
-    the in-place residual."""
+    +1, the pad columns of the map are the zero padding between rows (round 3).  NaN in every guard band and pad column of
+    the input (the kernel must mask what it reads there), map heights that are not multiples of 4, Cout = 32 / 64 / 128 / 384
+    blocks, the in-place residual; the output pad column is written as zero."""
     B, Cin, Cout, H, lp, affine, use_res = cfg
     P = 1 << lp
     x = _rand((B, Cin, H, P - 1), 311)

@@ -128,12 +128,11 @@ def main():
             wp = packing.pack_conv2d(torch.randn((cout, cin, 3, 3), generator=g) * (cin * 9) ** -0.5)
             w = wp.to(dev)
             wd = packing.pack_direct(wp).to(dev) if args.wd else None
-            wg2 = packing.pack_wino2d(wp).to(dev) if args.wg else None
             sc = torch.ones(cin, device=dev)
             sh = torch.zeros(cin, device=dev)
             a2 = ops.Act(pre=_lib.PRE_AFFINE_LRELU, pre_slope=0.01, scale=sc, shift=sh)
             wg42 = packing.pack_wino4_2d(wp).to(dev) if args.wg4 else None
-            fn = lambda: ops.conv2d(x, w, None, y, H, lp, 3, a2, wd=wd, wg=wg2, wg4=wg42)
+            fn = lambda: ops.conv2d(x, w, None, y, H, lp, 3, a2, wd=wd, wg4=wg42)
             macs = B * H * (P - 1) * cin * cout * 9
         fn()
         torch.cuda.synchronize()

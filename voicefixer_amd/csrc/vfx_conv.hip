@@ -1406,22 +1406,13 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
             bool ok = true;
             for (int t = 0; t < 9; ++t) ok &= phs[0].taps[t].off == (t / 3 - 1) * P + (t % 3 - 1) && phs[0].taps[t].slab == t;
             if (ok) rc4 = try_launch_convwg4s_2d(a, x, P, act->w_wino4, stream);
-            if (ok && rc4 == VFX_ENOTSUP) rc4 = try_launch_convwg4_2d(a, x, P, act->w_wino4, stream);
         } else {
             rc4 = try_launch_convwg4(a, x, nphase, phs, act->w_wino4, stream);
         }
         if (rc4 != VFX_ENOTSUP) return rc4;
     }
-    if (act && act->w_wino) {
-        int rcg = VFX_ENOTSUP;
-        if (nphase == 1 && phs[0].ntaps == 9 && in_mask > 0) {
-            const int P = in_mask + 1;
-            bool ok = true;
-            for (int t = 0; t < 9; ++t) ok &= phs[0].taps[t].off == (t / 3 - 1) * P + (t % 3 - 1) && phs[0].taps[t].slab == t;
-            if (ok) rcg = try_launch_convwg_2d(a, x, P, act->w_wino, stream);
-        } else {
-            rcg = try_launch_convwg(a, x, nphase, phs, act->w_wino, stream);
-        }
+    if (act && act->w_wino && !(nphase == 1 && phs[0].ntaps == 9)) {   // (F(2,3) serves 1-D launches only; 3x3: F(4,3) above)
+        const int rcg = try_launch_convwg(a, x, nphase, phs, act->w_wino, stream);
         if (rcg != VFX_ENOTSUP) return rcg;
     }
     if (act && act->w_direct) {

@@ -95,8 +95,7 @@ WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 # ... and, from this channel count on, on the F(4,3) kernel (convwg4_kernel: 2x fewer MFMAs than the direct sum; measured per
 # convolution at batch 32: C = 256 3.69 -> 3.09 ms, C = 512 2.18 -> 1.85 ms, C = 128 no gain: 8 chunks per tile are too few)
 WINO4_MIN_C = int(_os.environ.get("VFX_WINO4_MIN_C", "256"))
-WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"
-WINO4_2D = _os.environ.get("VFX_WINO4_2D", "1") != "0"   # F(4,3) for the 3x3 convolutions with Cout % 64 == 0   # the same for the 3x3 convolutions of the ResUNet (Cout % 64 == 0)
+WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
 
 
 class VocoderEngine:
@@ -261,15 +260,10 @@ class _ConvBlock:
         self.w1, self.w1d = _wpair(wp1, device)
         self.b1 = _dev(sh2, device)
         self.w2, self.w2d = _wpair(wp2, device)
-        # Winograd F(2,3) along the map rows (convwg_kernel, NKX = 3) where the kernel has an instance
-        # (instances: Cout % 64 == 0 with Cin % 32 == 0; Cout = 32 with Cin % 16 == 0)
-        cin_step = 32 if self.cout % 64 == 0 else 16
-        wino = WINO2D and self.cout % 32 == 0
-        self.w1g = _dev(packing.pack_wino2d(wp1), device) if wino and self.cin % cin_step == 0 else None
-        self.w2g = _dev(packing.pack_wino2d(wp2), device) if wino and self.cout % cin_step == 0 else None
-        # ... and F(4,3) (convwg4_kernel, NKX = 3) for the wide instances
-        # (convwg4s_kernel: 64-channel blocks with Cin % 32 == 0, or Cout = 32 -- UNet level 0 -- with Cin % 16 == 0)
-        wino4 = WINO2D and WINO4_2D and self.cout % 32 == 0
+        # Winograd F(4,3) along the map rows (convwg4s_kernel: 64-channel blocks with Cin % 32 == 0, or Cout = 32 -- UNet
+        # level 0 -- with Cin % 16 == 0); what it declines (the 2 -> 32 entry convolution, the deep levels' small
+        # launches) runs on the direct kernels
+        wino4 = WINO2D and self.cout % 32 == 0
         cin_step4 = 32 if self.cout % 64 == 0 else 16
         self.w1g4 = _dev(packing.pack_wino4_2d(wp1), device) if wino4 and self.cin % cin_step4 == 0 else None
         self.w2g4 = _dev(packing.pack_wino4_2d(wp2), device) if wino4 and self.cout % cin_step4 == 0 else None
@@ -301,9 +295,8 @@ class _ConvBlock:
             res = out
         else:
             res = x
-        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg=self.w1g,
-                   wg4=self.w1g4)
-        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg=self.w2g, wg4=self.w2g4)
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg4=self.w1g4)
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg4=self.w2g4)
 
 
 class RestorerEngine:

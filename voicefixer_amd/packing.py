@@ -89,19 +89,6 @@ def pack_wino4_2d(w_packed):
     return pack_direct(torch.stack(planes).float())
 
 
-def pack_wino2d(w_packed):
-    """[9][CinPad][Cout] (3x3 slabs ky*3 + kx) -> [12][CinPad/8][Cout][8], slab kx*4 + plane: the Winograd F(2,3) weight
-    transform along the kernel's ROW axis ky for every kernel column kx (convwg_kernel with NKX = 3, vfx_act.w_wino of
-    vfx_conv2d_f32): U[kx] = (w[0][kx], (w[0]+w[1]+w[2])[kx]/2, (w[0]-w[1]+w[2])[kx]/2, w[2][kx])."""
-    assert w_packed.shape[0] == 9
-    g = w_packed.double().reshape(3, 3, w_packed.shape[1], w_packed.shape[2])   # [ky][kx]
-    planes = []
-    for kx in range(3):
-        g0, g1, g2 = g[0, kx], g[1, kx], g[2, kx]
-        planes += [g0, (g0 + g1 + g2) * 0.5, (g0 - g1 + g2) * 0.5, g2]
-    return pack_direct(torch.stack(planes).float())
-
-
 def pack_cout1(w):
     """Conv weight (1, Cin, k[, 1]) -> [Cin][k]."""
     return w.reshape(w.shape[1], -1).contiguous().float()
