@@ -432,8 +432,8 @@ def main():
                 wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+>" % (wgm, 4 // wgm)
         if code == 80:
             wgm = bm // 32
-            return ("wino4", bm, bl), "convwg4_kernel<%d,%d> (Winograd F(4,3), %d ch x %d output quads)" % (
-                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d>" % (wgm, 4 // wgm)
+            return ("wino4", bm, bl), "convwg4_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; D1 = the dilation-1 instance)" % (
+                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, (true|false)>" % (wgm, 4 // wgm)
         if code == 70:
             wgm = bm // 32
             return ("wino", bm, bl), "convwg_kernel<%d,%d> (Winograd F(2,3), %d ch x %d output pairs)" % (

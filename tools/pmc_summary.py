@@ -6,8 +6,9 @@
 
 hbm : FETCH_SIZE / WRITE_SIZE come from two separate passes of the same bench command
       (gpurun refuses mixed trace domains; the guide asks for separate --pmc passes).  Both are
-      in KB; on gfx950 FETCH_SIZE undercounts wide coalesced loads by 2x (MI355X_MICROARCH.md, HBM
-      section), so bytes = (2*FETCH + WRITE) * 1024, averaged per launch.
+      in KB; on gfx950 FETCH_SIZE reports half of the bytes read (MI355X_MICROARCH.md, HBM section, for
+      16 B/lane loads; `calib` below measured the same factor for the dword buffer loads the Winograd
+      kernels issue), so bytes = (2*FETCH + WRITE) * 1024, averaged per launch.
 mfma: mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs * GRBM_GUI_ACTIVE / 8 XCDs).
 """
 import csv
@@ -54,15 +55,29 @@ def hbm(fetch_csv, write_csv, out):
         "lib_build_id": build_id(),
         "command": "rocprofv3 --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) --kernel-trace -- "
                    "python bench.py --steps 1 --warmup 1 --batch 32 --no-cpu-baseline",
-        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide (16 B/lane) coalesced loads "
-                      "-> doubled (MI355X_MICROARCH.md, HBM section); counters are KB",
+        "correction": "gfx950: FETCH_SIZE reports exactly 1/2 of the bytes read -- calibrated on this library's own "
+                      "access widths with tools/probe/fetch_calib.hip (1 GiB streams: dword buffer loads 0.5000, 16-byte "
+                      "buffer loads 0.5000; WRITE_SIZE exact for dword, 16-byte and half-wave-row dword stores: "
+                      "profiles/r03_fetch_size_calibration.json) -> bytes = (2*FETCH + WRITE) * 1024; counters are KB",
         "kernels": res,
     }
     json.dump(doc, open(out, "w"), indent=1)
 
 
-def mfma(m_csv, out):
+def durations(trace_csv):
+    """kernel name -> total duration (ns) and dispatch count, from the kernel_trace.csv of the SAME pass."""
+    tot = defaultdict(float)
+    cnt = defaultdict(int)
+    with open(trace_csv, newline="") as f:
+        for row in csv.DictReader(f):
+            tot[row["Kernel_Name"]] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            cnt[row["Kernel_Name"]] += 1
+    return tot, cnt
+
+
+def mfma(m_csv, out, trace_csv=None):
     m, n = read(m_csv)
+    dur = durations(trace_csv)[0] if trace_csv else {}
     res = {}
     for k, c in m.items():
         if not any(t in k for t in ("conv_taps", "convw", "gru", "stft", "conv_cout1")):
@@ -81,13 +96,19 @@ def mfma(m_csv, out):
             "wait_inst_frac": round(c.get("SQ_WAIT_INST_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
             "wait_any_frac": round(c.get("SQ_WAIT_ANY", 0.0) / max(c.get("SQ_WAVE_CYCLES", 1.0), 1.0), 3),
         }
+        if dur.get(k):
+            # shader clock while the kernel ran: cycles per XCD / duration, both from this pass
+            res[k]["shader_clock_ghz"] = round(gui / 8.0 / dur[k], 3)
+            res[k]["avg_launch_ms_in_this_pass"] = round(dur[k] / n[k] / 1e6, 4)
     doc = {
         "lib_build_id": build_id(),
         "command": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES "
                    "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -- python bench.py --steps 1 "
                    "--warmup 1 --batch 32 --no-cpu-baseline",
         "definition": "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); GRBM_GUI_ACTIVE "
-                      "is summed over the 8 XCDs; SQ_WAVE_CYCLES counts quad-cycles",
+                      "is summed over the 8 XCDs; SQ_WAVE_CYCLES counts quad-cycles; shader_clock_ghz = GRBM_GUI_ACTIVE / 8 / "
+                      "kernel duration of the same pass (the 157.3 TFLOP/s fp32-MFMA peak assumes 2.4 GHz: a time-based "
+                      "fraction of that peak is mfma_util x clock / 2.4)",
         "kernels": res,
     }
     json.dump(doc, open(out, "w"), indent=1)
@@ -121,4 +142,4 @@ if __name__ == "__main__":
     elif sys.argv[1] == "calib":
         calib(*sys.argv[2:5])
     else:
-        mfma(*sys.argv[2:4])
+        mfma(*sys.argv[2:5])

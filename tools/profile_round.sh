@@ -17,8 +17,20 @@ rocprofv3 --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_IN
 cd - > /dev/null
 F=$(find $OUT/pmc -name "fetch_counter_collection.csv" | head -1); W=$(find $OUT/pmc -name "write_counter_collection.csv" | head -1); M=$(find $OUT/pmc -name "m_counter_collection.csv" | head -1)
 python tools/pmc_summary.py hbm "$F" "$W" $OUT/pmc_hbm_traffic.json
-python tools/pmc_summary.py mfma "$M" $OUT/pmc_mfma_util.json
+MT=$(find $OUT/pmc -name "m_kernel_trace.csv" | head -1)
+python tools/pmc_summary.py mfma "$M" $OUT/pmc_mfma_util.json "$MT"
 S=$(find $OUT/stats -name "r_kernel_stats.csv" | head -1); cp "$S" $OUT/kernel_stats.csv
+# dispatch order and duration of every kernel of the LAST timed step (what the stats average over)
+T=$(find $OUT/stats -name "r_kernel_trace.csv" | head -1)
+python - "$T" $OUT/per_dispatch_last_step.txt <<'PY'
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void stft_mel_kernel")]
+with open(sys.argv[2], "w") as f:
+    f.write("# last step of the bench command under rocprofv3 --kernel-trace: kernel, duration (ms), in dispatch order\n")
+    for r in rows[starts[-1]:] if starts else rows:
+        f.write("%s\t%.3f\n" % (r["Kernel_Name"][:70], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+PY
 # keep the merge-back small: raw counter CSVs are large
 rm -rf $OUT/pmc $OUT/stats
 ls -la $OUT

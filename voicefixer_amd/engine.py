@@ -95,6 +95,9 @@ WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 # ... and, from this channel count on, on the F(4,3) kernel (convwg4_kernel: 2x fewer MFMAs than the direct sum; measured per
 # convolution at batch 32: C = 256 3.69 -> 3.09 ms, C = 512 2.18 -> 1.85 ms, C = 128 no gain: 8 chunks per tile are too few)
 WINO4_MIN_C = int(_os.environ.get("VFX_WINO4_MIN_C", "256"))
+# ... and the SECOND (dilation-1, residual-carrying) convolution of a layer from this channel count on: its quads are
+# aligned float4 in memory (convwg4_kernel's D1 instance: 16-byte tap / residual loads and stores)
+WINO4_D1_MIN_C = int(_os.environ.get("VFX_WINO4_D1_MIN_C", "128"))
 WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
 
 
@@ -137,7 +140,8 @@ class VocoderEngine:
                               ((_dev(packing.pack_wino(wa), device), _dev(packing.pack_wino(wb), device)) if wino
                                else (None, _dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C else None)) +
                               ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if wino4
-                               else (None, None)))
+                               else (None, _dev(packing.pack_wino4(wb), device)
+                                     if wino and WINO4_D1_MIN_C > 0 and cst >= WINO4_D1_MIN_C and cst % 128 == 0 else None)))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
