@@ -407,7 +407,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 16: conv_x3_kernel,
-    # 70 / 79: convwg_kernel (Winograd F(2,3): 1-D / 3x3 on pitch maps), 80: convwg4_kernel (Winograd F(4,3)), 71/72/74: fused layer with a Winograd second half,
+    # 80: convwg4_kernel (Winograd F(4,3), 1-D), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74: fused layer with a Winograd second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
     import re
@@ -434,24 +434,20 @@ def main():
             wgm = bm // 32
             return ("wino4", bm, bl), "convwg4_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; D1 = the dilation-1 instance)" % (
                 wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, (true|false)>" % (wgm, 4 // wgm)
-        if code == 70:
-            wgm = bm // 32
-            return ("wino", bm, bl), "convwg_kernel<%d,%d> (Winograd F(2,3), %d ch x %d output pairs)" % (
-                wgm, 4 // wgm, bm, bl // 2), r"convwg_kernel<%d, %d>" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
                r"conv_taps_kernel<%d, %d, \d+, \d+, %d," % (bm, bl, code)
 
-    # Arithmetic a family EXECUTES per multiply-accumulate of the direct convolution: the Winograd F(2,3) kernel
-    # forms 4 products per pair of outputs where the direct sum has 6.  `achieved` / `frac` below count executed MFMA
+    # Arithmetic a family EXECUTES per multiply-accumulate of the direct convolution: the Winograd F(4,3) kernels form
+    # 6 products per four outputs where the direct sum has 12.  `achieved` / `frac` below count executed MFMA
     # work (what the matrix pipe can be compared with); the direct-convolution equivalent is reported next to it.
     def exec_factor(key):
         if key[0] == "wino4":
             return 0.5         # six products per four outputs; the direct sum has twelve
         if key[0] == "wfusedw":
             return 5.0 / 6.0   # the dilated half direct (3 products per output), the dilation-1 half Winograd (2)
-        return 2.0 / 3.0 if key[0] == "wino" else 1.0
+        return 1.0
 
     by_fam = {}
     stft_bytes, stft_secs, stft_n = 0, 0.0, 0
@@ -512,9 +508,10 @@ def main():
                      for d in sorted(by_fam.values(), key=lambda d: -d[2])[:8]},
     }
     if xf != 1.0:
-        roofline["algorithm"] = ("Winograd %s along the dilated axis: %s; achieved / frac / algorithmic_gflop_per_launch "
-                                 "count the EXECUTED products" % (("F(4,3)", "6 fp32 MFMA products per 4 outputs instead of 12")
-                                                                if xf == 0.5 else ("F(2,3)", "4 fp32 MFMA products per output pair instead of 6")))
+        roofline["algorithm"] = ("Winograd F(4,3) along the dilated axis: 6 fp32 MFMA products per 4 outputs instead of 12; "
+                                 "achieved / frac / algorithmic_gflop_per_launch count the EXECUTED products"
+                                 if xf == 0.5 else "fused ResStack layer: dilated half direct, dilation-1 half Winograd F(2,3) on the "
+                                 "LDS tile (5 of 6 products); achieved / frac count the EXECUTED products")
         roofline["direct_conv_gflop_per_launch"] = round(2.0 * macs / launches / 1e9, 3)
         roofline["direct_equivalent_tflops"] = round(2.0 * macs / secs / 1e12, 2)
 
@@ -537,8 +534,8 @@ def main():
                                % (args.batch, args.seconds),
                    "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "frames": 1 + n // 441,
                    "arithmetic": ("fp32 operands, fp32 MFMA accumulation everywhere; k=3 / 3x3 convolutions evaluated as Winograd "
-                                  "F(4,3) / F(2,3) (DESIGN.md 3.0b: half / two thirds of the direct sum's products, rounding "
-                                  "~3x / ~1.2x the direct sum's; VFX_WINO=0 runs the direct sums)") if args.math == "f32"
+                                  "F(4,3) (F(2,3) inside the fused C=64 layer): half / two thirds of the direct sum's products, "
+                                  "rounding ~3x / ~1.2x the direct sum's (DESIGN.md 3.0b; VFX_WINO=0 runs the direct sums)") if args.math == "f32"
                                  else "opt-in split-bf16 products (three bf16 MFMAs per fp32 product), fp32 accumulation",
                    "parallelism": "utterance sharding x%d (no data-path collective)" % world},
         "path_tflops": round(2.0 * path_macs(n) * args.batch * world * args.steps / dt / 1e12, 2),

@@ -90,18 +90,14 @@ typedef struct {
                                on convw_kernel (weights read from L2 as MFMA A-operand vectors, activations staged
                                16-32 channels deep); bit-identical results are NOT implied (other summation order
                                within fp32 rounding).  Everything else, and small launches, use w_packed. */
-    const float* w_wino;    /* optional (may be NULL), k = 3 stride-1 Conv1d only: the Winograd F(2,3) transform of
-                               the three tap slabs, U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2, packed
-                               like w_direct with 4 slabs (packing.py::pack_wino).  Large launches with Cin % 32 == 0,
-                               Cout % 128 == 0, zero padding and no BatchNorm pre-activation then run on convwg_kernel:
-                               two outputs a dilation apart share four products instead of six (1.5x fewer fp32 MFMAs;
-                               the result differs from the direct sum by fp32 rounding only).  Ignored by
-                               vfx_conv2d_f32 (its 3x3 launches take w_wino4). */
-    const float* w_wino4;   /* optional (may be NULL), k = 3 stride-1 Conv1d: the Winograd F(4,3) transform, six
-                               slabs U = G w (packing.py::pack_wino4): four outputs a dilation apart share six products
-                               (2x fewer fp32 MFMAs than the direct sum; rounding error ~3x that of the direct sum, ~1e-6
-                               relative).  Tried before w_wino; same shape conditions.  For vfx_conv2d_f32 with ksize 3:
-                               the transform along the kernel's ROW axis for each kernel column, 18 slabs kx*6 + plane
+    const float* w_wino4;   /* optional (may be NULL), k = 3 stride-1 Conv1d: the Winograd F(4,3) transform of the three tap
+                               slabs, six slabs U = G w packed like w_direct (packing.py::pack_wino4).  Large launches (>=
+                               512 workgroups) with Cin % 32 == 0, Cout % 64 == 0, zero padding and no BatchNorm
+                               pre-activation then run on convwg4_kernel: four outputs a dilation apart share six
+                               products instead of twelve (2x fewer fp32 MFMAs than the direct sum; rounding ~3x the
+                               direct sum's, ~1e-6 relative, relative to the LARGEST operand of a quad's six-tap window:
+                               profiles/r03_winograd_error_sweep.txt).  For vfx_conv2d_f32 with ksize 3: the transform
+                               along the kernel's ROW axis for each kernel column, 18 slabs kx*6 + plane
                                (packing.py::pack_wino4_2d); launches with Cout % 64 == 0 and Cin % 32 == 0, or Cout % 32
                                == 0 and Cin % 16 == 0, on maps of pitch <= 64 / 128 run on convwg4s_kernel (four
                                vertically adjacent outputs share 18 products instead of 36). */
@@ -129,8 +125,7 @@ uint64_t vfx_launch_count(void);
  *   code 59           convw_kernel<BM,BL,*,*,NT=9,*,false>       (3x3 on a pitch map)
  *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels)
  *   code 71 / 72 / 74 convw_kernel<BM,BL,*,*,3,*,2>              (vfx_resblock2_f32: second half as Winograd F(2,3))
- *   code 70 / 79      convwg_kernel<..>                           (Winograd F(2,3): 1-D / 3x3 on a pitch map), BL = output positions
- *   code 80 / 89      convwg4_kernel<..>                          (Winograd F(4,3): 1-D / 3x3 on a pitch map)
+ *   code 80           convwg4_kernel<..>                          (Winograd F(4,3), 1-D), BL = output positions
  *   code 88           convwg4s_kernel<..>                         (Winograd F(4,3), 3x3 on a pitch map, kernel columns share one tile) */
 int vfx_last_conv_tile(void);
 
@@ -156,7 +151,8 @@ int vfx_conv1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias
 int vfx_resblock_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
                      const float* w2_direct, const float* bias2, int B, int C, int L, int dilation, float slope,
                      int post_act, float post_slope, vfx_stream_t stream);
-/* The same with the SECOND convolution's weights also given in the Winograd layout of vfx_act.w_wino (may be NULL): the
+/* The same with the SECOND convolution's weights also given as their Winograd F(2,3) transform (w2_wino, may be NULL:
+ * U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2, four slabs packed like w_direct, packing.py::pack_wino): the
  * dilation-1 half of the layer then forms 4 products per output pair instead of 6 on the LDS tile (C = 64 with the
  * 256-column tile, C = 128).  Results differ from vfx_resblock_f32 by fp32 rounding only. */
 int vfx_resblock2_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,

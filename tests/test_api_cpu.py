@@ -192,7 +192,7 @@ def _unpack_direct(wd):
 
 
 def test_pack_wino_is_the_f23_weight_transform():
-    """packing.pack_wino (vfx_act.w_wino): with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the inputs
+    """packing.pack_wino (vfx_resblock2_f32: w2_wino): with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the inputs
     x[q-d], x[q], x[q+d], x[q+2d] and m_k = U_k V_k, the pair (m0+m1+m2, m1-m2-m3) must be the direct k = 3 convolution
     at q and q + d -- evaluated here in float64 on the CPU from the PACKED weights."""
     import torch.nn.functional as F

@@ -285,47 +285,13 @@ WINO_CASES = [
 
 
 @pytest.mark.parametrize("case", WINO_CASES)
-def test_conv1d_winograd(case):
-    """convwg_kernel (vfx_act.w_wino): the k = 3 Conv1d as Winograd F(2,3) along the dilated axis -- four fp32 MFMA
-    products per output pair instead of six.  Against torch's direct fp32 conv1d at the tolerance of the direct
-    kernels; also no guard band is needed (taps outside the row are dropped by the buffer unit), nothing is written
-    past L, and the in-place residual update works."""
-    B, Cin, Cout, L, dil, pre, post, use_res = case
-    x = _rand((B, Cin, L), 161)
-    w = _rand((Cout, Cin, 3), 162, (Cin * 3) ** -0.5)
-    bias = _rand((Cout,), 163, 0.1)
-    res = _rand((B, Cout, L), 164) if use_res else None
-    ref = F.conv1d(_ref_act(x, pre, 0.01), w, bias, dilation=dil, padding=dil)
-    if use_res:
-        ref = ref + res
-    ref = _ref_post(ref, post, 0.2)
-    lp = (L + 67) // 4 * 4
-    xd = torch.full((B, Cin, lp), float("nan"), device=DEV)     # NO guard band; NaN right after the row
-    xd[:, :, :L] = x.to(DEV)
-    yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
-    rd = _padded(res, lp) if use_res else None
-    act = ops.Act(pre=pre, pre_slope=0.01, post=post, post_slope=0.2)
-    wp = packing.pack_conv1d(w)
-    wg = packing.pack_wino(wp).to(DEV)
-    before = _lib.lib().vfx_launch_count()
-    ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, rd, wg=wg)
-    torch.cuda.synchronize()
-    assert _lib.lib().vfx_launch_count() == before + 1
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 70, "launch did not run on convwg_kernel"
-    _close(yd[:, :, :L], ref, 2e-5)
-    assert torch.isnan(yd[:, :, L:]).all()
-    if use_res and post == _lib.POST_NONE:
-        rd2 = _padded(res, lp)   # in-place residual update (the engine's pattern for the unfused stages)
-        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), rd2, L, 3, dil, 0, act, rd2, wg=wg)
-        torch.cuda.synchronize()
-        _close(rd2[:, :, :L], ref, 2e-5)
-
-
-@pytest.mark.parametrize("case", WINO_CASES)
 def test_conv1d_winograd4(case):
-    """convwg4_kernel (vfx_act.w_wino4): the k = 3 Conv1d as Winograd F(4,3) -- six fp32 MFMA products per FOUR outputs.
-    Same contract as test_conv1d_winograd; the transform constants (up to 8) cost about three times the rounding error
-    of the direct sum (tools/winograd_error.py), still inside the tolerance of the direct kernels."""
+    """convwg4_kernel (vfx_act.w_wino4): the k = 3 Conv1d as Winograd F(4,3) along the dilated axis -- six fp32 MFMA
+    products per FOUR outputs instead of twelve.  Against torch's direct fp32 conv1d at the tolerance of the direct
+    kernels (the transform constants, up to 8, cost about three times the direct sum's rounding: tools/winograd_error.py);
+    no guard band is needed (taps outside the row are dropped by the buffer unit), nothing is written past L (NaN canaries),
+    the in-place residual update works.  Dilation 1 runs the D1 instance: quads as aligned 16-byte vectors, with the quad
+    that straddles the end of a row of odd length on single elements (L = 4099)."""
     B, Cin, Cout, L, dil, pre, post, use_res = case
     x = _rand((B, Cin, L), 261)
     w = _rand((Cout, Cin, 3), 262, (Cin * 3) ** -0.5)
@@ -380,37 +346,17 @@ def test_conv1d_winograd4_ragged_rows():
             assert torch.isnan(yd[r, :, n:]).all()
 
 
-def test_conv1d_winograd_ragged_rows_and_fallback():
-    """Per-row lengths: every row of a ragged launch equals the same row convolved alone (zero padding at ITS end);
-    small launches and shapes the kernel does not cover fall back to the direct kernels with the same result."""
-    B, C, L = 8, 256, 4100
-    lens = [4100, 4099, 2050, 2051, 3000, 54, 4047, 1]
-    x = _rand((B, C, L), 171)
-    w = _rand((C, C, 3), 172, (C * 3) ** -0.5)
-    bias = _rand((C,), 173, 0.1)
-    wp = packing.pack_conv1d(w)
-    wg = packing.pack_wino(wp).to(DEV)
-    act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01)
-    for dil in (27, 1):
-        xd = _guarded_nan(x, 8)
-        yd = torch.full((B, C, L + 60), float("nan"), device=DEV)
-        ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
-        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg=wg)
-        torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 == 70
-        for r, n in enumerate(lens):
-            ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
-            _close(yd[r:r + 1, :, :n], ref, 2e-5)
-            assert torch.isnan(yd[r, :, n:]).all()      # nothing is written past a row's own length
-    # fallbacks: a launch too small for the big tile, and Cout = 96
+def test_conv1d_winograd4_fallbacks():
+    """Launches the Winograd kernel declines -- too few workgroups for its tiles, Cout = 96 -- run on the direct kernels
+    with the same result."""
     for (b2, cin, cout, l2) in ((1, 256, 256, 900), (8, 64, 96, 4000)):
         x2 = _rand((b2, cin, l2), 174)
         w2 = _rand((cout, cin, 3), 175, (cin * 3) ** -0.5)
         wp2 = packing.pack_conv1d(w2)
         y2 = torch.full((b2, cout, l2 + 4), float("nan"), device=DEV)
-        ops.conv1d(_guarded_nan(x2, 300), wp2.to(DEV), None, y2, l2, 3, 3, 0, None, None, wg=packing.pack_wino(wp2).to(DEV))
+        ops.conv1d(_guarded_nan(x2, 300), wp2.to(DEV), None, y2, l2, 3, 3, 0, None, None, wg4=packing.pack_wino4(wp2).to(DEV))
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 != 70
+        assert _lib.lib().vfx_last_conv_tile() % 100 != 80
         _close(y2[:, :, :l2], F.conv1d(x2, w2, None, dilation=3, padding=3), 2e-5)
 
 
@@ -1102,9 +1048,8 @@ def _wino_adversarial_cases():
     return mod
 
 
-@pytest.mark.parametrize("which", ["wg4", "wg"])
-def test_winograd_kernels_on_adversarial_operand_statistics(which):
-    """convwg4_kernel / convwg_kernel against a FLOAT64 convolution on the operand statistics of tools/winograd_error.py
+def test_winograd_kernel_on_adversarial_operand_statistics():
+    """convwg4_kernel (its dilation-1 instance) against a FLOAT64 convolution on the operand statistics of tools/winograd_error.py
     --sweep (profiles/r03_winograd_error_sweep.txt): log-normal weight-norm row gains (sigma 1, 2), Student-t(2) entries,
     smooth and second-difference filters, per-channel log-normal activation scales, a DC offset 30x the spread, slowly
     varying inputs, 1e4 x outliers.  Bounds: the fp32 rounding the CPU restatement of the same arithmetic shows, x3 --
@@ -1113,7 +1058,7 @@ def test_winograd_kernels_on_adversarial_operand_statistics(which):
     mod = _wino_adversarial_cases()
     c, n, B = 256, 4096, 8
     gen = torch.Generator().manual_seed(0)
-    # (rms_rel, worst_row_rms_rel, max_over_mag) bounds = 3x the sweep's F(4,3) column (F(2,3) is tighter; one bound for both)
+    # (rms_rel, worst_row_rms_rel, max_over_mag) bounds = 3x the sweep's F(4,3) column
     for label, w, x in mod.cases(c, n, gen):
         w, x = w.float(), x.float()
         xin = x[:, : n + 2]                                    # y_dev[q] = sum_k w_k xin[q + k - 1]  (zero padding, dilation 1)
@@ -1125,10 +1070,9 @@ def test_winograd_kernels_on_adversarial_operand_statistics(which):
         xd[:, :, :L] = xin.to(DEV)[None]
         yd = torch.empty((B, c, lp), device=DEV)
         wp = packing.pack_conv1d(w)
-        kw = {"wg4": packing.pack_wino4(wp).to(DEV)} if which == "wg4" else {"wg": packing.pack_wino(wp).to(DEV)}
-        ops.conv1d(xd, wp.to(DEV), torch.zeros(c, device=DEV), yd, L, 3, 1, 0, None, None, **kw)
+        ops.conv1d(xd, wp.to(DEV), torch.zeros(c, device=DEV), yd, L, 3, 1, 0, None, None, wg4=packing.pack_wino4(wp).to(DEV))
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 == (80 if which == "wg4" else 70), "launch did not run on the Winograd kernel"
+        assert _lib.lib().vfx_last_conv_tile() % 100 == 80, "launch did not run on the Winograd kernel"
         y = yd[3, :, :L].cpu().double()
         assert torch.equal(yd[0, :, :L], yd[7, :, :L])         # identical rows: identical bits
         err = y - ref

@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--x3", action="store_true", help="VFX_MATH_BF16X3 (guarded inputs, 1-D shapes only)")
     ap.add_argument("--wd", action="store_true", help="offer the convw_kernel weight layout (vfx_act.w_direct)")
-    ap.add_argument("--wg", action="store_true", help="offer the Winograd F(2,3) weights (vfx_act.w_wino; k = 3 shapes); "
+    ap.add_argument("--wg", action="store_true", help="fused layers (rb*): the second half as Winograd F(2,3); "
                     "TFLOP/s stay the DIRECT algorithm's 2*MACs / time")
     ap.add_argument("--wg4", action="store_true", help="offer the Winograd F(4,3) weights (vfx_act.w_wino4; k = 3 1-D shapes)")
     args = ap.parse_args()
@@ -90,9 +90,8 @@ def main():
             bias = torch.zeros(cout, device=dev)
             pad = 1 if kind == "c1r" else 0
             wd = packing.pack_direct(wp).to(dev) if args.wd else None
-            wg = packing.pack_wino(wp).to(dev) if (args.wg and k == 3) else None
             wg4 = packing.pack_wino4(wp).to(dev) if (args.wg4 and k == 3) else None
-            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd, wg=wg, wg4=wg4)
+            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd, wg4=wg4)
             macs = B * L * cin * cout * k
         elif kind == "rb":
             x = ops.guarded(B, cin, L, 2187 + 264, dev)

@@ -25,7 +25,7 @@ class vfx_tensor(C.Structure):
 class vfx_act(C.Structure):
     _fields_ = [("pre_act", C.c_int), ("pre_slope", C.c_float), ("pre_scale", C.c_void_p),
                 ("pre_shift", C.c_void_p), ("post_act", C.c_int), ("post_slope", C.c_float),
-                ("math", C.c_int), ("w_x3", C.c_void_p), ("w_direct", C.c_void_p), ("w_wino", C.c_void_p), ("w_wino4", C.c_void_p)]
+                ("math", C.c_int), ("w_x3", C.c_void_p), ("w_direct", C.c_void_p), ("w_wino4", C.c_void_p)]
 
 
 PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU = 0, 1, 2

@@ -1411,10 +1411,6 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         }
         if (rc4 != VFX_ENOTSUP) return rc4;
     }
-    if (act && act->w_wino && !(nphase == 1 && phs[0].ntaps == 9)) {   // (F(2,3) serves 1-D launches only; 3x3: F(4,3) above)
-        const int rcg = try_launch_convwg(a, x, nphase, phs, act->w_wino, stream);
-        if (rcg != VFX_ENOTSUP) return rcg;
-    }
     if (act && act->w_direct) {
         int rcw = VFX_ENOTSUP;
         if (nphase == 1 && phs[0].ntaps == 9 && in_mask > 0) {

@@ -85,19 +85,14 @@ import os as _os
 # development switches: VFX_FUSE=0 runs every ResStack layer as two launches, VFX_CONVW=0 (read by the library)
 # keeps every launch on the first-generation kernel
 _FUSE = _os.environ.get("VFX_FUSE", "1") != "0"
-FUSE_MAX_C = 128  # ResStack stages with at most this many channels can run one fused launch per layer
-# ResStack stages with at least this many channels run their k = 3 convolutions on the Winograd F(2,3) kernel
-# (convwg_kernel: 1.5x fewer fp32 MFMAs; needs Cout % 64 == 0).  Measured per layer at batch 32, two Winograd launches
-# against the fused direct layer (vfx_resblock_f32): C = 128 5.9 ms against 7.4 ms; C = 64 7.2 ms against 6.3 ms (the
-# second launch reads the intermediate AND the residual from HBM: 10.9 GB, bandwidth-bound) -- so the C = 64 stage
-# keeps the fused layer.  VFX_WINO_MIN_C=64 / 0: development switch.
+FUSE_MAX_C = 128  # ResStack stages with at most this many channels CAN run one fused launch per layer
+# ResStack stages with at least this many channels run their two k = 3 convolutions per layer as two Winograd F(4,3)
+# launches (convwg4_kernel: half the fp32 MFMAs of the direct sum; the dilation-1 one moves its quads as 16-byte
+# vectors).  Measured per step at batch 32, one box, round 3: C = 128 on F(4,3) for both convolutions 235.3 ms, with the
+# round-2 F(2,3) kernel for the first 238.5 ms; C = 64 as two F(4,3) launches 235.2 ms against 235.3 ms fused (its
+# second launch reads the intermediate AND the residual from HBM) -- so C = 64 keeps the fused layer, whose dilation-1
+# half is F(2,3) on the LDS tile.  VFX_WINO_MIN_C=64 / 0: development switch.
 WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
-# ... and, from this channel count on, on the F(4,3) kernel (convwg4_kernel: 2x fewer MFMAs than the direct sum; measured per
-# convolution at batch 32: C = 256 3.69 -> 3.09 ms, C = 512 2.18 -> 1.85 ms, C = 128 no gain: 8 chunks per tile are too few)
-WINO4_MIN_C = int(_os.environ.get("VFX_WINO4_MIN_C", "256"))
-# ... and the SECOND (dilation-1, residual-carrying) convolution of a layer from this channel count on: its quads are
-# aligned float4 in memory (convwg4_kernel's D1 instance: 16-byte tap / residual loads and stores)
-WINO4_D1_MIN_C = int(_os.environ.get("VFX_WINO4_D1_MIN_C", "128"))
 WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
 
 
@@ -118,7 +113,7 @@ class VocoderEngine:
         for i in (0, 2, 4, 6, 8):
             p = "condnet.%d" % i
             wc = packing.pack_conv1d(wn(p))
-            wcg = (_dev(packing.pack_wino(wc), device)
+            wcg = (_dev(packing.pack_wino4(wc), device)
                    if WINO_MIN_C > 0 and wc.shape[1] % 32 == 0 and wc.shape[2] % 64 == 0 else None)
             self.condnet.append(_wpair(wc, device) + (_dev(sd[p + ".bias"], device), wcg))
         self.pre = (_dev(packing.pack_conv1d(wn("generator.1")), device), _dev(sd["generator.1.bias"], device))
@@ -134,14 +129,12 @@ class VocoderEngine:
                 a = "%s.layers.%d.1" % (rs, i)
                 b = "%s.layers.%d.3" % (rs, i)
                 wa, wb = packing.pack_conv1d(wn(a)), packing.pack_conv1d(wn(b))
-                wino4 = wino and WINO4_MIN_C > 0 and cst >= WINO4_MIN_C
+                # (w1, w1d, b1, w2, w2d, b2, w2 as F(2,3) for the fused layer's LDS half, w1 / w2 as F(4,3) for two launches)
                 layers.append(_wpair(wa, device) + (_dev(sd[a + ".bias"], device),) +
                               _wpair(wb, device) + (_dev(sd[b + ".bias"], device),) +
-                              ((_dev(packing.pack_wino(wa), device), _dev(packing.pack_wino(wb), device)) if wino
-                               else (None, _dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C else None)) +
-                              ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if wino4
-                               else (None, _dev(packing.pack_wino4(wb), device)
-                                     if wino and WINO4_D1_MIN_C > 0 and cst >= WINO4_D1_MIN_C and cst % 128 == 0 else None)))
+                              (_dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C and not wino else None,) +
+                              ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if wino
+                               else (None, None)))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -181,7 +174,7 @@ class VocoderEngine:
         for i, (w, wd, bias, wg) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
             ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w), wd=wd,
-                       wg=wg if self.math == "f32" else None)
+                       wg4=wg if self.math == "f32" else None)
             x = y
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
@@ -198,7 +191,7 @@ class VocoderEngine:
             mult *= s
             # (the fused kernel addresses one batch item with 32-bit byte offsets: rows of more than ~3 minutes at the last
             # stage fall back to the two-launch form, whose first-generation kernel has no such limit)
-            wino = layers[0][6] is not None and self.math == "f32"
+            wino = layers[0][7] is not None and self.math == "f32"
             fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and not wino and
                      c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
             xs = _rows(B, c, Lo, G_DIL, dev, rows(mult))
@@ -206,7 +199,7 @@ class VocoderEngine:
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
-            for i, (w1, w1d, b1, w2, w2d, b2, w1g, w2g, w1g4, w2g4) in enumerate(layers):
+            for i, (w1, w1d, b1, w2, w2d, b2, w2g, w1g4, w2g4) in enumerate(layers):
                 last = i == len(layers) - 1
                 if fused:
                     # one launch per layer, intermediate tile in LDS; input and output ping-pong between xs and ys
@@ -218,11 +211,10 @@ class VocoderEngine:
                     ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=w2g)
                     continue
                 if not wino:
-                    w1g = w2g = w1g4 = w2g4 = None
-                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg=w1g, wg4=w1g4)
+                    w1g4 = w2g4 = None
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg4=w1g4)
                 act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
-                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg=w2g,
-                           wg4=w2g4)  # residual updated in place
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg4=w2g4)  # residual updated in place
             assert len(layers) % 2 == 0  # the fused ping-pong ends in xs
             h = xs
             L = Lo

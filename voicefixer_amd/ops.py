@@ -103,35 +103,34 @@ _NOACT = None
 _ACTVARIANTS = {}
 
 
-def _act(a, w3=None, wd=None, wg=None, wg4=None):
+def _act(a, w3=None, wd=None, wg4=None):
     """vfx_act* for a launch.  ``w3`` (packing.pack_x3 planes on the device) opts the launch into VFX_MATH_BF16X3 (the
     library falls back to fp32 for geometries its bf16x3 kernel does not cover); ``wd`` (packing.pack_direct on the
-    device) offers the fp32 launch the convw_kernel weight layout (vfx_act.w_direct; the library decides); ``wg``
-    (packing.pack_wino on the device) offers a k = 3 launch the Winograd F(2,3) kernel (vfx_act.w_wino)."""
+    device) offers the fp32 launch the convw_kernel weight layout (vfx_act.w_direct; the library decides); ``wg4``
+    (packing.pack_wino4 / pack_wino4_2d on the device) offers a k = 3 / 3x3 launch the Winograd F(4,3) kernels
+    (vfx_act.w_wino4)."""
     global _NOACT
     if a is None:
         if _NOACT is None:
             _NOACT = Act()
         a = _NOACT
-    if w3 is None and wd is None and wg is None and wg4 is None:
+    if w3 is None and wd is None and wg4 is None:
         return C.byref(a.c)
     key = (id(a), w3.data_ptr() if w3 is not None else 0, wd.data_ptr() if wd is not None else 0,
-           wg.data_ptr() if wg is not None else 0, wg4.data_ptr() if wg4 is not None else 0)
+           wg4.data_ptr() if wg4 is not None else 0)
     ent = _ACTVARIANTS.get(key)
     if ent is None:
         c = vfx_act(a.c.pre_act, a.c.pre_slope, a.c.pre_scale, a.c.pre_shift, a.c.post_act, a.c.post_slope,
                     MATH_BF16X3 if w3 is not None else MATH_F32, w3.data_ptr() if w3 is not None else None,
-                    wd.data_ptr() if wd is not None else None, wg.data_ptr() if wg is not None else None,
-                    wg4.data_ptr() if wg4 is not None else None)
-        ent = _ACTVARIANTS[key] = (c, a, w3, wd, wg, wg4)  # keep the owners alive with the struct
+                    wd.data_ptr() if wd is not None else None, wg4.data_ptr() if wg4 is not None else None)
+        ent = _ACTVARIANTS[key] = (c, a, w3, wd, wg4)  # keep the owners alive with the struct
     return C.byref(ent[0])
 
 
-def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None, wd=None,
-           wg=None, wg4=None):
+def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=None, cin=None, w3=None, wd=None, wg4=None):
     """x (B,Cin,>=L) -> y (B,Cout,>=L) views; w packed [k][CinPad][Cout].  Optional weight layouts the library may use
     instead (it decides per launch, see include/vfx_hip.h: vfx_act): w3 = bf16x3 planes (opts the launch into that
-    arithmetic), wd = packing.pack_direct, wg / wg4 = the Winograd F(2,3) / F(4,3) transforms (k = 3 only)."""
+    arithmetic), wd = packing.pack_direct, wg4 = the Winograd F(4,3) transform (k = 3 only)."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
     cin = x.shape[1] if cin is None else cin
@@ -140,7 +139,7 @@ def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=Non
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3, wd, wg, wg4), _stream())
+                                   C.byref(yd), B, cin, cout, L, k, dilation, pad_mode, _act(act, w3, wd, wg4), _stream())
     check(rc, "vfx_conv1d_f32")
     _prof_end(e0, B * L * cin * cout * k)
 
@@ -170,7 +169,7 @@ def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None, wd=None):
     _prof_end(e0, B * Lin * cin * cout * 2 * stride)
 
 
-def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3=None, wd=None, wg=None, wg4=None):
+def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3=None, wd=None, wg4=None):
     """x (B,Cin,H*P) pitch map -> y (B,Cout,H*P)."""
     _need_cuda(x, w, y, res, bias)
     B = x.shape[0]
@@ -180,7 +179,7 @@ def conv2d(x, w, bias, y, H, pitch_log2, ksize, act=None, res=None, cin=None, w3
     rd = tdesc(res) if res is not None else None
     e0 = _prof_begin()
     rc = _lib.lib().vfx_conv2d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(rd) if rd is not None else None,
-                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act, w3, wd, wg, wg4), _stream())
+                                   C.byref(yd), B, cin, cout, H, pitch_log2, ksize, _act(act, w3, wd, wg4), _stream())
     check(rc, "vfx_conv2d_f32")
     _prof_end(e0, B * H * ((1 << pitch_log2) - 1) * cin * cout * ksize * ksize)
 
