@@ -1084,3 +1084,34 @@ def test_winograd_kernel_on_adversarial_operand_statistics():
         assert row_rel < (4e-5 if ill else 2e-5), (label, row_rel)
         if "outliers" not in label:
             assert over_mag < 3e-5, (label, over_mag)
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 147294, 1), (2, 256, 147294, 27), (2, 128, 441882, 1)])
+def test_conv1d_winograd4_long_rows(cfg):
+    """Rows as long as a 30 s segment produces them (147 294 / 441 882 positions: > 64 tiles, so the XCD-aware tile order
+    and the channel-block fold are active; lengths that are not multiples of 4, so the dilation-1 instance meets its
+    straddling quad), batch 2, with and without the in-place residual.  The short cases of test_conv1d_winograd4 run
+    in linear tile order; a round-3 epilogue variant that was wrong only on long rows of a batch > 1 passed all of them."""
+    B, C, L, dil = cfg
+    x = _rand((B, C, L), 801)
+    w = _rand((C, C, 3), 802, (C * 3) ** -0.5)
+    bias = _rand((C,), 803, 0.1)
+    res = _rand((B, C, L), 804)
+    ref0 = F.conv1d(F.leaky_relu(x, 0.01), w, bias, dilation=dil, padding=dil)
+    lp = (L + 3) // 4 * 4
+    xd = torch.full((B, C, lp + 64), float("nan"), device=DEV)
+    xd[:, :, :L] = x.to(DEV)
+    wp = packing.pack_conv1d(w)
+    wg4 = packing.pack_wino4(wp).to(DEV)
+    act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01)
+    for use_res in (False, True):
+        yd = torch.full((B, C, lp + 64), float("nan"), device=DEV)
+        rd = None
+        if use_res:
+            yd[:, :, :L] = res.to(DEV)
+            rd = yd[:, :, :lp]                      # in place
+        ops.conv1d(xd[:, :, :lp], wp.to(DEV), bias.to(DEV), yd[:, :, :lp], L, 3, dil, 0, act, rd, wg4=wg4)
+        torch.cuda.synchronize()
+        assert _lib.lib().vfx_last_conv_tile() % 100 == 80
+        _close(yd[:, :, :L], ref0 + res if use_res else ref0, 2e-5)
+        assert torch.isnan(yd[:, :, L:]).all()      # nothing written past the rows
