@@ -161,6 +161,24 @@ def test_wav_length_from_header(tmp_path):
         assert audio_io.wav_length(p) == len(audio_io.load_wav(p))
 
 
+def test_resample_hq_meets_the_soxr_hq_recipe():
+    """Other sample rates (voicefixer/base.py:47-49: librosa.load(sr=44100), soxr_hq by default): tones in the pass
+    band (up to 0.913 of the lower Nyquist frequency) come out at the new rate to 1e-6, tones above that Nyquist frequency
+    are rejected by more than 120 dB, and the length is the ceil(n * ratio) the header-based planner predicts."""
+    for sr_in in (48000, 16000, 96000):
+        n = sr_in
+        t = np.arange(n) / sr_in
+        f_nyq = min(sr_in, audio_io.SR) / 2
+        for f in (440.0, 0.9 * f_nyq):
+            y = audio_io.resample_hq(np.sin(2 * np.pi * f * t), sr_in, audio_io.SR)
+            assert len(y) == -(-n * audio_io.SR // sr_in) and y.dtype == np.float32
+            ref = np.sin(2 * np.pi * f * np.arange(len(y)) / audio_io.SR)
+            assert np.abs(y[3000:-3000] - ref[3000:-3000]).max() < 1e-6, (sr_in, f)
+        if sr_in > audio_io.SR:
+            y = audio_io.resample_hq(np.sin(2 * np.pi * (f_nyq + 60.0) * t), sr_in, audio_io.SR)
+            assert np.sqrt(np.mean(y[3000:-3000].astype(np.float64) ** 2)) < 1e-6 / np.sqrt(2)     # -120 dB re the tone
+
+
 def test_plan_batches_ragged_runs():
     """restore_batch's batch plan: ascending lengths -> runs of <= batch_size utterances whose shortest member has at
     least ragged_ratio of the frames of the longest; multi-segment files and plugin vocoders fall back to exact

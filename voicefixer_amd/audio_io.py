@@ -4,8 +4,10 @@ Mirrors voicefixer/tools/wav.py: ``save_wave`` (:9-37, int16 truncation) and the
 ``librosa.load(path, sr=44100)`` call of voicefixer/base.py:47-49.  librosa / soundfile are not
 available offline, so WAV files are read with scipy/stdlib, FLAC files (the format of the reference's own
 test fixtures, test/test.py:45-75) with the decoder / encoder of ``flac.py``, and other sample rates are resampled with a
-polyphase filter (librosa would use soxr_hq: resampled inputs are NOT bit-identical to the reference's;
-44.1 kHz inputs are).
+linear-phase polyphase filter designed to the published soxr "HQ" recipe librosa.load uses by default (pass band to
+0.913 of the lower Nyquist frequency, stop band from that Nyquist frequency on, 125 dB rejection: ``resample_hq``).  Same
+grade, not the same coefficients: resampled inputs agree with the reference's to the filter ripple, not bit for bit;
+44.1 kHz inputs are untouched.
 """
 import struct
 
@@ -89,6 +91,28 @@ def wav_length(path, sample_rate=SR):
     return -(-n * up // down)  # resample_poly: ceil(n * up / down)
 
 
+_HQ_FILTERS = {}
+
+
+def resample_hq(x, sr_in, sr_out):
+    """Band-limited rate conversion along the last axis, ceil(n * sr_out / sr_in) samples (librosa.load(sr=...) ->
+    soxr_hq).  One Kaiser-windowed sinc at the common rate up * sr_in: pass band edge 0.913 and stop band edge 1.0 of
+    the lower of the two Nyquist frequencies, 125 dB (beta = 0.1102 (A - 8.7), length from Kaiser's estimate), applied
+    as a polyphase filter (scipy's upfirdn never forms the zero-stuffed signal)."""
+    from math import gcd
+    from scipy.signal import firwin, resample_poly
+    g = gcd(int(sr_in), int(sr_out))
+    up, down = int(sr_out) // g, int(sr_in) // g
+    h = _HQ_FILTERS.get((up, down))
+    if h is None:
+        m = max(up, down)                      # the lower Nyquist frequency is 1 / m of the common rate's
+        att, f_pass, f_stop = 125.0, 0.913 / m, 1.0 / m
+        taps = int(np.ceil((att - 7.95) / (2.285 * np.pi * (f_stop - f_pass)))) | 1    # odd: zero phase
+        h = firwin(taps, 0.5 * (f_pass + f_stop), window=("kaiser", 0.1102 * (att - 8.7)))       # (resample_poly applies the gain `up`)
+        _HQ_FILTERS[(up, down)] = h
+    return resample_poly(np.asarray(x, dtype=np.float64), up, down, axis=-1, window=h).astype(np.float32)
+
+
 def load_wav(path, sample_rate=SR, mono=True):
     """Decode + (if needed) resample + downmix, float32 in [-1, 1] (librosa.load semantics)."""
     low = str(path).lower()
@@ -113,8 +137,5 @@ def load_wav(path, sample_rate=SR, mono=True):
     if x.ndim == 2:
         x = x.mean(axis=1) if mono else x.T
     if sr != sample_rate:
-        from math import gcd
-        from scipy.signal import resample_poly
-        g = gcd(int(sr), int(sample_rate))
-        x = resample_poly(x, sample_rate // g, sr // g, axis=-1).astype(np.float32)
+        x = resample_hq(x, sr, sample_rate)
     return np.ascontiguousarray(x, dtype=np.float32)
