@@ -232,8 +232,25 @@ def scatter_job(args, pipe, n, rank, world, dev, dist):
                          for r, x in enumerate(allt)],
             "path_tflops": round(2.0 * path_macs(n) * n_utt / dmax / 1e12, 2),
         }
-        print(json.dumps(line), flush=True)
+        _json_line_last(line)
     dist.destroy_process_group()
+
+
+def _json_line_last(line):
+    """Print the ONE JSON line as the last thing this job writes to stdout: librccl prints a version banner through C
+    stdio (block-buffered on a pipe, so it would surface at exit, AFTER the line) -- flush that first, print, then send
+    whatever native code still writes to fd 1 to stderr."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+    print(json.dumps(line), flush=True)
+    try:
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(2, 1)
+    except OSError:
+        pass
 
 
 def _free_port():
@@ -325,6 +342,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if rank != 0:
+        os.dup2(2, 1)   # only rank 0 owns stdout (the JSON line); whatever native libraries print elsewhere goes to stderr
     requested = int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus))
     if args.dry_run:
         return dry_run(args, rank, world)
@@ -575,7 +594,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(args, ring[last_idx][0].cpu().numpy(), out[0].cpu())
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        _json_line_last(line)
     if dist is not None:
         dist.destroy_process_group()
 

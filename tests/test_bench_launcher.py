@@ -19,6 +19,7 @@ def _run(*extra, env=None):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout       # rank 0 prints ONE JSON line
+    assert r.stdout.strip().splitlines()[-1] == lines[0], r.stdout   # ... and nothing follows it on stdout
     return json.loads(lines[0]), r.stderr
 
 
