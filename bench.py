@@ -487,7 +487,7 @@ def main():
     launches, macs, secs, kname, krx, xf = max(by_fam.values(), key=lambda d: d[2])
     achieved = 2.0 * macs * xf / secs / 1e12
     # HBM bytes per launch of that family: PMC counters cannot be read live; they come from the committed rocprofv3
-    # --pmc passes over this same command (tools/profile_round.sh -> profiles/r02_pmc_hbm_traffic_bench_b32.json)
+    # --pmc passes over this same command (tools/profile_round.sh -> profiles/r03_pmc_hbm_traffic_bench_b32.json)
     # -- and only when that summary was taken with THIS library: the summary carries vfx_build_id() of the build it
     # profiled; a kernel change without a re-profile reports traffic = null and says why
     traffic, traffic_note = None, None
