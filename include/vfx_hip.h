@@ -125,6 +125,7 @@ uint64_t vfx_launch_count(void);
  *   code 59           convw_kernel<BM,BL,*,*,NT=9,*,false>       (3x3 on a pitch map)
  *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels)
  *   code 71 / 72 / 74 convw_kernel<BM,BL,*,*,3,*,2>              (vfx_resblock2_f32: second half as Winograd F(2,3))
+ *   code 91 / 92 / 94 convw_kernel<BM,BL,*,*,3,*,3>              (vfx_resblock3_f32: second half as Winograd F(4,3))
  *   code 80           convwg4_kernel<..>                          (Winograd F(4,3), 1-D), BL = output positions
  *   code 88           convwg4s_kernel<..>                         (Winograd F(4,3), 3x3 on a pitch map, kernel columns share one tile) */
 int vfx_last_conv_tile(void);
@@ -158,6 +159,14 @@ int vfx_resblock_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_d
 int vfx_resblock2_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
                       const float* w2_direct, const float* bias2, const float* w2_wino, int B, int C, int L,
                       int dilation, float slope, int post_act, float post_slope, vfx_stream_t stream);
+/* The same, with the second convolution's weights also offered as their Winograd F(4,3) transform (w2_wino4, may be NULL:
+ * six slabs U = G w as for vfx_act.w_wino4, packing.py::pack_wino4).  C = 64 with 16-byte aligned rows of x and y: the
+ * dilation-1 half forms 6 products per output QUAD instead of 12 (63 quads per 256-column tile; residual and stores move
+ * as 16-byte vectors).  Anything else falls back to w2_wino / the direct weights as vfx_resblock2_f32 does. */
+int vfx_resblock3_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
+                      const float* w2_direct, const float* bias2, const float* w2_wino, const float* w2_wino4,
+                      int B, int C, int L, int dilation, float slope, int post_act, float post_slope,
+                      vfx_stream_t stream);
 
 /* ConvTranspose1d(Cin, Cout, kernel 2s, stride s, padding s/2 + s%2, output_padding s%2):
  * Lin -> s*Lin.  Polyphase: s phases x 2 taps.  w_packed = [2s][CinPad][Cout], slab k is

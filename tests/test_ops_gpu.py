@@ -405,6 +405,10 @@ RESBLOCK_CASES = [
     (1, 64, 254, 1, _lib.POST_NONE),           # exactly one tile of 254 outputs
     (1, 64, 255, 1, _lib.POST_NONE),
     (1, 64, 1, 1, _lib.POST_NONE),
+    (1, 64, 251, 3, _lib.POST_NONE),           # F(4,3) second half: 252 outputs (63 quads) per tile
+    (1, 64, 252, 1, _lib.POST_LRELU),
+    (2, 64, 506, 1, _lib.POST_NONE),           # two tiles and half a quad
+    (2, 64, 20002, 9, _lib.POST_LRELU_SNAKE),
     (2, 128, 9000, 1, _lib.POST_NONE),
     (2, 128, 9001, 3, _lib.POST_LRELU),
     (2, 128, 9000, 27, _lib.POST_NONE),
@@ -457,6 +461,31 @@ def test_resblock_fused(case):
     _close(yd2[:, :, :L], ref, 2e-5)
     base = yd2._vfx_base
     assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()
+    if Cn != 64:
+        return
+    # ... and as Winograd F(4,3): wave = 32 channels x 32 output quads, residual and stores as 16-byte vectors, the quad
+    # that straddles the end of a row of odd length as single elements (vfx_resblock3_f32, w2_wino4)
+    yd3 = ops.guarded(B, Cn, L, 2187 + 264, DEV)
+    yd3._vfx_base.fill_(float("nan"))
+    ops.resblock(xd, yd3, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2,
+                 w2g=packing.pack_wino(packing.pack_conv1d(w2)).to(DEV),
+                 w2g4=packing.pack_wino4(packing.pack_conv1d(w2)).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (91, 92, 94)
+    _close(yd3[:, :, :L], ref, 2e-5)
+    base = yd3._vfx_base
+    assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()
+    # rows that are not 16-byte aligned fall back to the F(2,3) form
+    if L > 8:
+        yo = ops.guarded(B, Cn, L + 4, 2187 + 264, DEV)
+        yv = yo[:, :, 1:1 + L]
+        yv._vfx_guard, yv._vfx_base = yo._vfx_guard, yo._vfx_base
+        ops.resblock(xd, yv, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2,
+                     w2g=packing.pack_wino(packing.pack_conv1d(w2)).to(DEV),
+                     w2g4=packing.pack_wino4(packing.pack_conv1d(w2)).to(DEV))
+        torch.cuda.synchronize()
+        assert _lib.lib().vfx_last_conv_tile() % 100 in (71, 72, 74)
+        _close(yv, ref, 2e-5)
 
 
 

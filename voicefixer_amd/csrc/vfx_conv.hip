@@ -111,7 +111,7 @@ struct ConvArgs {
     int kcx;                // channels per activation chunk (8, 16 or 32)
     int ntiles_l, xcd_chunk;      // tiles along L; XCD-aware tile order: tiles per XCD (0 = linear order)
     int nph_fold;                 // convw_kernel, transposed convolutions: phases folded into blockIdx.x (0 = phase in blockIdx.y)
-    int wg_d;                     // convwg_kernel (Winograd F(2,3) along the dilated axis): the dilation
+    int wg_d;                     // convwg4_kernel (Winograd F(4,3) along the dilated axis): the dilation
     const int* x_rows;            // ragged batches: valid input length of batch item b (device int32[B]) or NULL (= Lin)
     int lq_extra;                 // ... its valid output-position count is x_rows[b] + lq_extra (1 for transposed 1-D convs)
     int stagger, stagger_wgs;     // development: start stagger of the first residency round (s_sleep units, workgroups)

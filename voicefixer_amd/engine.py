@@ -129,12 +129,13 @@ class VocoderEngine:
                 a = "%s.layers.%d.1" % (rs, i)
                 b = "%s.layers.%d.3" % (rs, i)
                 wa, wb = packing.pack_conv1d(wn(a)), packing.pack_conv1d(wn(b))
-                # (w1, w1d, b1, w2, w2d, b2, w2 as F(2,3) for the fused layer's LDS half, w1 / w2 as F(4,3) for two launches)
+                # (w1, w1d, b1, w2, w2d, b2, w2 as F(2,3) for the fused layer's LDS half, w1 / w2 as F(4,3) for two launches --
+                # the fused C = 64 layer takes w2 as F(4,3) too: its LDS half runs on it, F(2,3) is the fallback)
                 layers.append(_wpair(wa, device) + (_dev(sd[a + ".bias"], device),) +
                               _wpair(wb, device) + (_dev(sd[b + ".bias"], device),) +
                               (_dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C and not wino else None,) +
                               ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if wino
-                               else (None, None)))
+                               else (None, _dev(packing.pack_wino4(wb), device) if cst == 64 else None)))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -208,7 +209,7 @@ class VocoderEngine:
                     if last:
                         post, pslope = (POST_LRELU if j == nst - 1 else POST_LRELU_SNAKE), 0.2
                     src, dst = (xs, ys) if i % 2 == 0 else (ys, xs)
-                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=w2g)
+                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=w2g, w2g4=w2g4)
                     continue
                 if not wino:
                     w1g4 = w2g4 = None
