@@ -534,8 +534,8 @@ def main():
     if xf != 1.0:
         roofline["algorithm"] = ("Winograd F(4,3) along the dilated axis: 6 fp32 MFMA products per 4 outputs instead of 12; "
                                  "achieved / frac / algorithmic_gflop_per_launch count the EXECUTED products"
-                                 if xf == 0.5 else "fused ResStack layer: dilated half direct, dilation-1 half Winograd F(2,3) on the "
-                                 "LDS tile (5 of 6 products); achieved / frac count the EXECUTED products")
+                                 if xf == 0.5 else "fused ResStack layer: dilated half direct, dilation-1 half Winograd on the LDS tile "
+                                 "(F(4,3): 3 of 4 products, F(2,3): 5 of 6); achieved / frac count the EXECUTED products")
         roofline["direct_conv_gflop_per_launch"] = round(2.0 * macs / launches / 1e9, 3)
         roofline["direct_equivalent_tflops"] = round(2.0 * macs / secs / 1e12, 2)
 

@@ -228,7 +228,7 @@ def test_heavy_tailed_weight_norm_gains_whole_path(sigma):
     """Every other parity test draws weight-norm gains from U[0.9, 1.1] x |v| and BatchNorm scales from U[0.8, 1.2].
     Trained checkpoints are not like that (w = g v / |v| with heavy-tailed g): here every gain is log-normal, exp(sigma z -
     sigma^2), i.e. rows from ~exp(-sigma^2 - 3 sigma) to ~exp(3 sigma - sigma^2) of the nominal scale, through the WHOLE path
-    at a batch that puts the Winograd F(4,3) / F(2,3) kernels and the fused layer to work (transform constants up to 8 on
+    at a batch that puts the Winograd F(4,3) kernels and the fused layer (F(4,3) on its LDS tile) to work (transform constants up to 8 on
     inputs of very different scale per channel), against the CPU oracle on the same state dicts."""
     from voicefixer_amd import weights
     vsd = weights.seeded_vocoder_state(77, gain_sigma=sigma)

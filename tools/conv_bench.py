@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--wd", action="store_true", help="offer the convw_kernel weight layout (vfx_act.w_direct)")
     ap.add_argument("--wg", action="store_true", help="fused layers (rb*): the second half as Winograd F(2,3); "
                     "TFLOP/s stay the DIRECT algorithm's 2*MACs / time")
-    ap.add_argument("--wg4", action="store_true", help="offer the Winograd F(4,3) weights (vfx_act.w_wino4; k = 3 1-D shapes)")
+    ap.add_argument("--wg4", action="store_true", help="offer the Winograd F(4,3) weights (vfx_act.w_wino4; k = 3 1-D shapes; fused C = 64 layers: their second half)")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -100,9 +100,10 @@ def main():
             w1d = packing.pack_direct(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
             w2d = packing.pack_direct(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
             bias = torch.zeros(cout, device=dev)
-            w2g = (packing.pack_wino(packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)).to(dev)
-                   if args.wg else None)
-            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil, w2g=w2g)
+            w2p = packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)
+            w2g = packing.pack_wino(w2p).to(dev) if args.wg else None
+            w2g4 = packing.pack_wino4(w2p).to(dev) if (args.wg4 and cin == 64) else None
+            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil, w2g=w2g, w2g4=w2g4)
             macs = 2 * B * L * cin * cout * 3
         elif kind == "t1":
             s = k

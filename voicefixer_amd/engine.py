@@ -91,7 +91,8 @@ FUSE_MAX_C = 128  # ResStack stages with at most this many channels CAN run one 
 # vectors).  Measured per step at batch 32, one box, round 3: C = 128 on F(4,3) for both convolutions 235.3 ms, with the
 # round-2 F(2,3) kernel for the first 238.5 ms; C = 64 as two F(4,3) launches 235.2 ms against 235.3 ms fused (its
 # second launch reads the intermediate AND the residual from HBM) -- so C = 64 keeps the fused layer, whose dilation-1
-# half is F(2,3) on the LDS tile.  VFX_WINO_MIN_C=64 / 0: development switch.
+# half then moved to F(4,3) on the LDS tile as well (229.0 -> 223.5 ms; F(2,3) is its fallback for unaligned rows).
+# VFX_WINO_MIN_C=64 / 0: development switch.
 WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
 
