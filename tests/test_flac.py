@@ -104,3 +104,230 @@ def test_wav_length_from_header_any_bit_depth(tmp_path):
     assert x.shape == (777,) and np.allclose(x, vals / float(1 << 23), atol=1e-6)
     wavfile.write(f22, 22050, np.zeros(1000, np.int16))
     assert audio_io.wav_length(f22) == len(audio_io.load_wav(f22)) == 2000
+
+
+# ---- the C frame codec (voicefixer_amd/csrc_host/vfx_flac.c, include/vfx_audio.h) against the Python specification ----
+@pytest.fixture(scope="module")
+def native_codec():
+    flac.build_native()                       # one C file, about a second
+    h = flac.native()
+    if h is None:
+        pytest.skip("libvfx_audio.so switched off (VFX_FLAC_NATIVE=0)")
+    return h
+
+
+def test_native_library_exports_the_header(native_codec):
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "vfx_audio.h")).read()
+    names = set(re.findall(r"\b(vfx_[a-z0-9_]+)\s*\(", hdr))
+    assert names == {"vfx_audio_version", "vfx_flac_decode_frames", "vfx_flac_encode_frames"}
+    for n in names:
+        getattr(native_codec, n)              # AttributeError == header / library mismatch
+
+
+@pytest.mark.parametrize("name", ["original_original.flac", "original_p360_001_mic1.flac", "target_oracle.flac",
+                                  "target_output_mode_0.flac", "target_output_mode_1.flac"])
+def test_native_decoder_equals_the_python_decoder_on_the_reference_fixtures(native_codec, name):
+    data = open(os.path.join(REF, name), "rb").read()      # libFLAC streams: LPC subframes, partitioned Rice codes
+    a = flac.decode(data, use_native=False)
+    b = flac.decode(data, use_native=True)
+    assert a[0] == b[0] and a[2] == b[2] and a[1].dtype == b[1].dtype and np.array_equal(a[1], b[1])
+    bad = bytearray(data)
+    bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(flac.FlacError):
+        flac.decode(bytes(bad), use_native=True)            # CRC-16 (or a broken code) is caught in C as well
+    with pytest.raises(flac.FlacError):
+        flac.decode(data[:len(data) // 2], use_native=True)  # truncated stream
+
+
+@pytest.mark.parametrize("n, nch, bps", [(0, 1, 16), (1, 1, 16), (2, 2, 16), (3, 1, 16), (4095, 1, 16), (4096, 2, 16),
+                                         (4097, 1, 24), (20000, 2, 24), (9000, 1, 8), (12345, 3, 12), (5000, 2, 20)])
+def test_native_encoder_writes_the_python_encoder_s_bytes(native_codec, n, nch, bps):
+    rng = np.random.default_rng(n + nch + bps)
+    t = np.arange(n)[:, None]
+    amp = (1 << (bps - 1)) - 1
+    x = 0.4 * amp * np.sin(2 * np.pi * 220.0 * (1 + np.arange(nch)) * t / 44100.0) + 0.01 * amp * rng.standard_normal((n, nch))
+    x[n // 2:n // 2 + 700] = amp * rng.uniform(-1, 1, x[n // 2:n // 2 + 700].shape)     # a stretch of noise: VERBATIM frames
+    pcm = np.clip(np.round(x), -amp - 1, amp).astype(np.int64)
+    e_py = flac.encode(pcm, 44100, bps, use_native=False)
+    e_c = flac.encode(pcm, 44100, bps, use_native=True)
+    assert e_py == e_c
+    for use in (False, True):
+        sr, back, b = flac.decode(e_c, use_native=use)
+        assert (sr, b) == (44100, bps) and np.array_equal(back, pcm.reshape(n, nch))
+
+
+class _BitWriter:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, v, n):
+        self.bits += [(int(v) >> (n - 1 - i)) & 1 for i in range(n)]
+
+    def signed(self, v, n):
+        self.put(int(v) & ((1 << n) - 1), n)
+
+    def rice(self, v, k):
+        u = 2 * v if v >= 0 else -2 * v - 1
+        self.put(0, u >> k)
+        self.put(1, 1)
+        self.put(u & ((1 << k) - 1), k)
+
+    def align(self):
+        self.bits += [0] * (-len(self.bits) % 8)
+
+    def bytes(self):
+        assert len(self.bits) % 8 == 0
+        return np.packbits(np.array(self.bits, np.uint8)).tobytes()
+
+
+def _lpc_residual(x, coefs, shift):
+    order = len(coefs)
+    res = []
+    for i in range(order, len(x)):
+        pred = sum(int(c) * int(x[i - 1 - j]) for j, c in enumerate(coefs)) >> shift
+        res.append(int(x[i]) - pred)
+    return res
+
+
+def _handmade_stream(sub_specs, cassign, chans, bps, blocksize):
+    """One-frame stream with hand-written subframes.  sub_specs[c] = ("constant" | "verbatim" | ("fixed", order, porder,
+    escape_partition) | ("lpc", coefs, shift, precision), wasted_bits); chans[c] = what subframe c carries."""
+    w = _BitWriter()
+    w.put(0x3FFE, 14); w.put(0, 2)
+    w.put(7, 4); w.put(0, 4)                      # 16-bit block size follows; sample rate from STREAMINFO
+    w.put(cassign, 4); w.put({8: 1, 12: 2, 16: 4, 20: 5, 24: 6}[bps], 3); w.put(0, 1)
+    w.put(0, 8)                                   # frame number 0
+    w.put(blocksize - 1, 16)
+    w.put(flac._crc8(w.bytes()), 8)
+    side = {8: (1,), 9: (0,), 10: (1,)}.get(cassign, ())
+    for c, ((kind, wasted), x) in enumerate(zip(sub_specs, chans)):
+        sb = bps + (1 if c in side else 0) - wasted
+        x = [int(v) >> wasted for v in x]
+        w.put(0, 1)
+        typ = {"constant": 0, "verbatim": 1}.get(kind) if isinstance(kind, str) else \
+            (8 + kind[1] if kind[0] == "fixed" else 31 + len(kind[1]))
+        w.put(typ, 6)
+        if wasted:
+            w.put(1, 1); w.put(0, wasted - 1); w.put(1, 1)
+        else:
+            w.put(0, 1)
+        if kind == "constant":
+            w.signed(x[0], sb)
+        elif kind == "verbatim":
+            for v in x:
+                w.signed(v, sb)
+        else:
+            if kind[0] == "fixed":
+                order, porder, esc_part = kind[1], kind[2], kind[3]
+                coefs, shift = flac._FIXED[order], 0
+            else:
+                coefs, shift, prec = kind[1], kind[2], kind[3]
+                order, porder, esc_part = len(coefs), 1, -1
+            for v in x[:order]:
+                w.signed(v, sb)
+            if kind[0] == "lpc":
+                w.put(prec - 1, 4); w.signed(shift, 5)
+                for cf in coefs:
+                    w.signed(cf, prec)
+            res = _lpc_residual(x, coefs, shift)
+            w.put(1, 2); w.put(porder, 4)             # Rice method 1: 5-bit parameters, escape code 31
+            o = 0
+            for part in range(1 << porder):
+                cnt = (blocksize >> porder) - (order if part == 0 else 0)
+                seg = res[o:o + cnt]
+                o += cnt
+                if part == esc_part:
+                    nb = max(int(abs(v)).bit_length() for v in seg) + 1
+                    w.put(31, 5); w.put(nb, 5)
+                    for v in seg:
+                        w.signed(v, nb)
+                else:
+                    k = 3 + part
+                    w.put(k, 5)
+                    for v in seg:
+                        w.rice(v, k)
+    w.align()
+    frame = w.bytes()
+    frame += struct.pack(">H", flac._crc16(frame))
+    nch = len(chans)
+    v = (44100 << 44) | ((nch - 1) << 41) | ((bps - 1) << 36) | blocksize
+    si = struct.pack(">HH", blocksize, blocksize) + len(frame).to_bytes(3, "big") * 2 + v.to_bytes(8, "big") + bytes(16)
+    return b"fLaC" + bytes([0x80]) + len(si).to_bytes(3, "big") + si + frame
+
+
+@pytest.mark.parametrize("cassign", [1, 8, 9, 10])
+def test_both_decoders_on_handmade_subframes(native_codec, cassign):
+    """What neither the reference's (mono, libFLAC) fixtures nor our own encoder produce: CONSTANT subframes, FIXED
+    orders other than 2, partitioned residuals with an escape partition, LPC with a shift, wasted bits, and the three
+    stereo decorrelation modes -- written bit by bit here, decoded by the Python and the C decoder."""
+    rng = np.random.default_rng(cassign)
+    bs, bps = 64, 16
+    left = (3000 * np.sin(np.arange(bs) / 5.0) + rng.integers(-40, 40, bs)).astype(np.int64)
+    right = (left * 0.9 + rng.integers(-300, 300, bs)).astype(np.int64)
+    left4 = (left >> 2) << 2                                   # two wasted bits
+    cases = [
+        ([("verbatim", 0), (("fixed", 4, 1, -1), 0)], left, right),
+        ([(("fixed", 1, 2, 2), 0), (("lpc", (1200, -400, 37), 10, 12), 0)], left, right),
+        ([(("fixed", 3, 0, -1), 2), (("fixed", 0, 1, 0), 0)], left4, right),
+        ([("constant", 0), (("lpc", (2047, -1024), 11, 12), 0)], np.full(bs, -1234), right),
+    ]
+    for specs, a, b in cases:
+        if cassign == 1:
+            chans = want = [a, b]
+        elif cassign == 8:
+            chans, want = [a, a - b], [a, b]
+        elif cassign == 9:
+            chans, want = [a - b, b], [a, b]
+        else:
+            mid, sd = (a + b) >> 1, a - b
+            chans, want = [mid, sd], [a, b]
+            if specs[0][1]:                                    # wasted bits belong to the CODED channel: keep mid divisible
+                a2 = ((mid >> specs[0][1]) << specs[0][1]) * 2 + (sd & 1) + sd
+                a = a2 >> 1
+                b = a - sd
+                mid = (a + b) >> 1
+                chans, want = [mid, sd], [a, b]
+        if specs[0][0] == "constant" and cassign != 1:
+            continue                                           # (a constant mid / side channel would change `want`)
+        if specs[0][1] and cassign in (8, 9):
+            chans[0] = (np.asarray(chans[0]) >> specs[0][1]) << specs[0][1]
+            want = [chans[0], chans[0] - chans[1]] if cassign == 8 else [chans[0] + chans[1], chans[1]]
+        data = _handmade_stream(specs, cassign, chans, bps, bs)
+        for use in (False, True):
+            sr, pcm, b_ = flac.decode(data, use_native=use)
+            assert (sr, b_) == (44100, bps)
+            assert np.array_equal(pcm[:, 0], want[0]) and np.array_equal(pcm[:, 1], want[1]), (cassign, specs, use)
+
+
+def test_native_codec_runs_without_the_interpreter_lock(native_codec):
+    """The point of the C codec: restore_folder's worker threads decode / encode files in parallel, because ctypes drops
+    the interpreter lock around the call.  Shown without a stopwatch: a pure-Python thread keeps counting WHILE one
+    long native decode is in flight (it could not execute a single bytecode if the lock were held)."""
+    import threading
+    rng = np.random.default_rng(3)
+    n = 44100 * 240
+    pcm = (8000 * np.sin(np.arange(n) / 30.0) + rng.integers(-200, 200, n)).astype(np.int64)
+    data = flac.encode(pcm, 44100, 16, use_native=True)
+    state = {"count": 0, "stop": False, "during": None}
+
+    def spin():
+        while not state["stop"]:
+            state["count"] += 1
+
+    th = threading.Thread(target=spin)
+    th.start()
+    try:
+        import ctypes
+        out = np.empty((n, 1), np.int32)
+        done, err = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        before = state["count"]
+        rc = native_codec.vfx_flac_decode_frames(data, len(data), 42, 1, 16, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)),
+                                                 n, ctypes.byref(done), 1, ctypes.byref(err))      # ~0.15 s in C
+        state["during"] = state["count"] - before
+    finally:
+        state["stop"] = True
+        th.join()
+    assert rc == 0 and done.value == n and np.array_equal(out[:, 0], pcm)
+    assert state["during"] > 10000, state["during"]          # (holding the lock it would be 0; free-running: millions)

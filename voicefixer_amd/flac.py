@@ -13,10 +13,18 @@ image, so the subset of the format those files use is implemented here from the 
              (parameter chosen per subframe; VERBATIM where Rice would be longer), independent channels, block size
              4096, MD5 and total-sample count in STREAMINFO, CRC-8 / CRC-16 on every frame.
 
-Rice decoding is sequential by nature; it runs as a Python loop over precomputed per-bit tables (about a second per
-100 k samples).  Good enough for the fixtures and for occasional files; bulk folders should be WAV.
+Two implementations of the frame level, bit-exact against each other in both directions (tests/test_flac.py):
+  * this module -- the specification in Python (Rice decoding is sequential by nature: a loop over precomputed per-bit
+    tables, ~14x real time per thread, under the interpreter lock);
+  * ``libvfx_audio.so`` (voicefixer_amd/csrc_host/vfx_flac.c, C ABI include/vfx_audio.h, built by
+    ``__graft_entry__.build()``) -- the same decoder / encoder in C, several hundred times real time per thread and
+    called through ctypes WITHOUT the interpreter lock, which is what lets restore_folder's worker pool keep up with the
+    device.  ``decode`` / ``encode`` use it when it is there (``VFX_FLAC_NATIVE=0``: never); metadata blocks,
+    STREAMINFO, the MD5 check and argument checking are shared Python code either way.
 """
+import ctypes
 import hashlib
+import os
 import struct
 
 import numpy as np
@@ -24,6 +32,62 @@ import numpy as np
 
 class FlacError(RuntimeError):
     pass
+
+
+# ---------------------------------------------------------------------------------------------------- native codec
+_NATIVE = None          # None = not looked for yet, False = unavailable / switched off, else the ctypes handle
+_NATIVE_ERRORS = {2: "FLAC: lost frame sync at byte %d", 3: "FLAC: frame header CRC-8 mismatch at byte %d",
+                  4: "FLAC: frame CRC-16 mismatch in the frame at byte %d", 5: "FLAC: reserved field in the frame at byte %d",
+                  6: "FLAC: Rice code runs past the end of the stream (frame at byte %d)",
+                  7: "FLAC: channel count changes mid-stream (frame at byte %d)",
+                  8: "FLAC: more samples than STREAMINFO announces (frame at byte %d)", 9: "FLAC: out of memory (frame at byte %d)"}
+
+
+def build_native(verbose=False):
+    """Compile libvfx_audio.so in-tree (``make -C voicefixer_amd/csrc_host``: one C file, gcc); returns its path."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run(["make", "-C", os.path.join(here, "csrc_host")], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-2000:])
+        print(r.stderr[-2000:])
+    if r.returncode != 0:
+        raise FlacError("building libvfx_audio.so failed (gcc)")
+    global _NATIVE
+    _NATIVE = None
+    return os.path.join(here, "libvfx_audio.so")
+
+
+def native():
+    """ctypes handle of libvfx_audio.so, or None (not built, or VFX_FLAC_NATIVE=0)."""
+    global _NATIVE
+    if _NATIVE is None:
+        _NATIVE = False
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfx_audio.so")
+        if os.environ.get("VFX_FLAC_NATIVE", "1") != "0" and os.path.exists(path):
+            h = ctypes.CDLL(path)
+            u8p, i32p = ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int)
+            ull, ullp = ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong)
+            h.vfx_audio_version.restype = ctypes.c_int
+            h.vfx_flac_decode_frames.restype = ctypes.c_int
+            h.vfx_flac_decode_frames.argtypes = [ctypes.c_char_p, ull, ull, ctypes.c_int, ctypes.c_int, i32p, ull, ullp,
+                                                 ctypes.c_int, ullp]
+            h.vfx_flac_encode_frames.restype = ctypes.c_longlong
+            h.vfx_flac_encode_frames.argtypes = [i32p, ull, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ull,
+                                                 ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+            if h.vfx_audio_version() >= 100:
+                _NATIVE = h
+    return _NATIVE or None
+
+
+def _decode_frames_native(h, data, pos, nch, bps0, total, verify):
+    out = np.empty((total, nch), dtype=np.int32)
+    done, err_at = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+    rc = h.vfx_flac_decode_frames(data, len(data), pos, nch, bps0, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), total,
+                                  ctypes.byref(done), 1 if verify else 0, ctypes.byref(err_at))
+    if rc:
+        raise FlacError(_NATIVE_ERRORS.get(rc, "FLAC: decoder error %d (frame at byte %%d)" % rc) % err_at.value)
+    return out[:done.value]
 
 
 def _crc_table(poly, bits):
@@ -232,8 +296,9 @@ _BLOCK = {1: 192, 2: 576, 3: 1152, 4: 2304, 5: 4608, 8: 256, 9: 512, 10: 1024, 1
 _BPS = {1: 8, 2: 12, 4: 16, 5: 20, 6: 24, 7: 32}
 
 
-def decode(data, verify=True):
-    """bytes of a FLAC file -> (sample_rate, int32 array (n, channels), bits per sample)."""
+def decode(data, verify=True, use_native=None):
+    """bytes of a FLAC file -> (sample_rate, int32 array (n, channels), bits per sample).  ``use_native``: None = the C
+    frame decoder when it is built, False = the Python one, True = the C one (None if unavailable -> Python)."""
     if data[:4] != b"fLaC":
         raise FlacError("not a FLAC stream (missing fLaC marker)")
     pos = 4
@@ -252,6 +317,10 @@ def decode(data, verify=True):
     if info is None:
         raise FlacError("FLAC: no STREAMINFO block")
     nch, bps0 = info["ch"], info["bps"]
+    h = native() if use_native is None else (native() if use_native else None)
+    if h is not None and info["total"] > 0 and 4 <= bps0 <= 32:
+        pcm = _decode_frames_native(h, bytes(data), pos, nch, bps0, info["total"], verify)
+        return _finish_decode(pcm, info, bps0, verify)
     br = _Bits(data)
     br.pos = pos << 3
     chans = [[] for _ in range(nch)]
@@ -319,6 +388,10 @@ def decode(data, verify=True):
         for c in range(nch):
             chans[c].extend(sub[c])
     pcm = np.array(chans, dtype=np.int64).T
+    return _finish_decode(pcm, info, bps0, verify)
+
+
+def _finish_decode(pcm, info, bps0, verify):
     if info["total"] and pcm.shape[0] != info["total"]:
         raise FlacError("FLAC: decoded %d samples, STREAMINFO says %d" % (pcm.shape[0], info["total"]))
     if verify and any(info["md5"]):
@@ -416,8 +489,9 @@ def _put(arr, off, value, nbits):
         arr[off + b] = (value >> (nbits - 1 - b)) & 1
 
 
-def encode(pcm, sample_rate, bps=16, blocksize=4096):
-    """int array (n,) or (n, channels), values inside the signed ``bps``-bit range -> bytes of a FLAC file."""
+def encode(pcm, sample_rate, bps=16, blocksize=4096, use_native=None):
+    """int array (n,) or (n, channels), values inside the signed ``bps``-bit range -> bytes of a FLAC file.
+    ``use_native`` as in ``decode`` (both encoders write the same bytes)."""
     pcm = np.asarray(pcm)
     if pcm.ndim == 1:
         pcm = pcm[:, None]
@@ -430,6 +504,17 @@ def encode(pcm, sample_rate, bps=16, blocksize=4096):
     zcode = {8: 1, 12: 2, 16: 4, 20: 5, 24: 6}.get(bps)
     if zcode is None:
         raise FlacError("FLAC: unsupported bits per sample %d" % bps)
+    h = native() if use_native is None else (native() if use_native else None)
+    if h is not None and n:
+        p32 = np.ascontiguousarray(pcm, dtype=np.int32)
+        cap = n * nch * 4 + 32 * (n // blocksize + 2) + 64
+        buf = np.empty(cap, dtype=np.uint8)
+        mn, mx = ctypes.c_uint(0), ctypes.c_uint(0)
+        nb = h.vfx_flac_encode_frames(p32.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), n, nch, bps, blocksize,
+                                      buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)), cap, ctypes.byref(mn), ctypes.byref(mx))
+        if nb < 0:
+            raise FlacError("FLAC: encoder error %d" % -nb)
+        return _stream(pcm, sample_rate, nch, bps, n, blocksize, mn.value, mx.value, buf[:nb].tobytes())
     frames = []
     min_f, max_f = 1 << 24, 0
     for fi, s0 in enumerate(range(0, n, blocksize)):
@@ -449,11 +534,16 @@ def encode(pcm, sample_rate, bps=16, blocksize=4096):
         min_f, max_f = min(min_f, len(frame)), max(max_f, len(frame))
     if not frames:
         min_f = max_f = 0
+    return _stream(pcm, sample_rate, nch, bps, n, blocksize, min_f, max_f, b"".join(frames))
+
+
+def _stream(pcm, sample_rate, nch, bps, n, blocksize, min_f, max_f, frames):
+    """fLaC marker + STREAMINFO (the only metadata block) + the frames."""
     md5 = hashlib.md5(_pcm_bytes(pcm, bps)).digest()
     v = (sample_rate << 44) | ((nch - 1) << 41) | ((bps - 1) << 36) | n
     si = struct.pack(">HH", blocksize, blocksize) + min_f.to_bytes(3, "big") + max_f.to_bytes(3, "big") + \
         v.to_bytes(8, "big") + md5
-    return b"fLaC" + bytes([0x80]) + len(si).to_bytes(3, "big") + si + b"".join(frames)
+    return b"fLaC" + bytes([0x80]) + len(si).to_bytes(3, "big") + si + frames
 
 
 def write(path, pcm, sample_rate, bps=16):
