@@ -331,3 +331,27 @@ def test_native_codec_runs_without_the_interpreter_lock(native_codec):
         th.join()
     assert rc == 0 and done.value == n and np.array_equal(out[:, 0], pcm)
     assert state["during"] > 10000, state["during"]          # (holding the lock it would be 0; free-running: millions)
+
+
+def test_native_decoder_survives_corrupted_streams(native_codec):
+    """Bit flips, overwritten bytes and truncations: the C decoder either decodes or reports an error (FlacError) --
+    tools/flac_fuzz.py runs the same under -fsanitize=address,undefined (profiles/r03_flac_codec_fuzz.txt)."""
+    rng = np.random.default_rng(5)
+    src = open(os.path.join(REF, "target_oracle.flac"), "rb").read()
+    rejected = 0
+    for _ in range(300):
+        d = bytearray(src)
+        for _ in range(int(rng.integers(1, 5))):
+            pos = int(rng.integers(38, len(d)))
+            mode = int(rng.integers(0, 3))
+            if mode == 0:
+                d[pos] ^= 1 << int(rng.integers(0, 8))
+            elif mode == 1:
+                d[pos] = int(rng.integers(0, 256))
+            else:
+                d = d[:pos]
+        try:
+            flac.decode(bytes(d), use_native=True)
+        except flac.FlacError:
+            rejected += 1
+    assert rejected > 250          # (with the CRCs and the MD5 on, only damage past the last frame goes unnoticed)

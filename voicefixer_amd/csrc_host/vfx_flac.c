@@ -147,11 +147,16 @@ static int residual(br_t* b, int blocksize, int order, int64_t* out) {
     return 0;
 }
 
+/* (sums in uint64_t: a valid stream never leaves 64 bits -- 33-bit samples x 15-bit coefficients x 32 taps -- and a corrupt
+ * one, which the CRC-16 rejects afterwards, wraps instead of overflowing a signed type) */
+static inline int64_t wadd(int64_t a, int64_t b) { return (int64_t)((uint64_t)a + (uint64_t)b); }
+static inline int64_t wsub(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+
 static void predict(int64_t* x, int order, const int64_t* c, int shift, int n) {
     for (int i = order; i < n; ++i) {
-        int64_t s = 0;
-        for (int j = 0; j < order; ++j) s += c[j] * x[i - 1 - j];
-        x[i] += s >> shift;     /* arithmetic shift of the integer dot product, as the format defines */
+        uint64_t s = 0;
+        for (int j = 0; j < order; ++j) s += (uint64_t)c[j] * (uint64_t)x[i - 1 - j];
+        x[i] = wadd(x[i], (int64_t)s >> shift);     /* arithmetic shift of the integer dot product, as the format defines */
     }
 }
 
@@ -256,15 +261,15 @@ int vfx_flac_decode_frames(const unsigned char* data, unsigned long long len, un
             if (!rc) rc = subframe(&b, blocksize, bps + (cassign == 9 ? 0 : 1), ch[1]);
             if (!rc) {
                 if (cassign == 8) {             /* left, side */
-                    for (int i = 0; i < blocksize; ++i) ch[1][i] = ch[0][i] - ch[1][i];
+                    for (int i = 0; i < blocksize; ++i) ch[1][i] = wsub(ch[0][i], ch[1][i]);
                 } else if (cassign == 9) {      /* side, right */
-                    for (int i = 0; i < blocksize; ++i) ch[0][i] = ch[0][i] + ch[1][i];
+                    for (int i = 0; i < blocksize; ++i) ch[0][i] = wadd(ch[0][i], ch[1][i]);
                 } else {                        /* mid, side */
                     for (int i = 0; i < blocksize; ++i) {
                         const int64_t s = ch[1][i];
                         const int64_t m = (int64_t)((uint64_t)ch[0][i] << 1) | (s & 1);
-                        ch[0][i] = (m + s) >> 1;
-                        ch[1][i] = (m - s) >> 1;
+                        ch[0][i] = wadd(m, s) >> 1;
+                        ch[1][i] = wsub(m, s) >> 1;
                     }
                 }
             }

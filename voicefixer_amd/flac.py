@@ -304,10 +304,14 @@ def decode(data, verify=True, use_native=None):
     pos = 4
     info = None
     while True:
+        if pos + 4 > len(data):
+            raise FlacError("FLAC: the stream ends inside the metadata blocks")
         hdr = data[pos]
         length = int.from_bytes(data[pos + 1:pos + 4], "big")
         body = data[pos + 4:pos + 4 + length]
         pos += 4 + length
+        if pos > len(data) or (hdr & 0x7F == 0 and length < 34):
+            raise FlacError("FLAC: the stream ends inside the metadata blocks")
         if hdr & 0x7F == 0:
             v = int.from_bytes(body[10:18], "big")
             info = {"sr": v >> 44, "ch": ((v >> 41) & 7) + 1, "bps": ((v >> 36) & 31) + 1, "total": v & ((1 << 36) - 1),
