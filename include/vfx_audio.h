@@ -1,4 +1,5 @@
-/* vfx_audio.h -- C ABI of libvfx_audio.so: the native FLAC frame codec behind voicefixer_amd/flac.py (host side).
+/* vfx_audio.h -- C ABI of libvfx_audio.so: the native FLAC frame codec behind voicefixer_amd/flac.py and the polyphase
+ * resampler behind voicefixer_amd/audio_io.py (host side).
  *
  * Replaces, for the folder driver's decode / encode workers, what the reference reaches through
  * librosa.load (voicefixer/base.py:47-49) and soundfile.write (voicefixer/tools/wav.py:36-37): libsndfile's FLAC
@@ -42,6 +43,14 @@ int vfx_flac_decode_frames(const unsigned char* data, unsigned long long len, un
  * *min_frame / *max_frame = the smallest / largest frame in bytes (STREAMINFO fields). */
 long long vfx_flac_encode_frames(const int* pcm, unsigned long long n, int nch, int bps, int blocksize,
                                  unsigned char* out, unsigned long long cap, unsigned* min_frame, unsigned* max_frame);
+
+/* Polyphase rate conversion (what librosa.load(sr=44100) does inside the reference, voicefixer/base.py:47-49):
+ *   y[m] = sum_k g[c + m*down - k*up] * x[k],  c = (L - 1) / 2,  m < ny
+ * g = the L-tap (L odd) zero-phase low-pass at the common rate up * fs_in, already scaled by up; x has n samples (zero
+ * outside).  This is scipy.signal.resample_poly(x, up, down, window=g / up) in float32 with one dot product per output
+ * sample.  Returns 0 or VFX_FLAC_EINVAL / VFX_FLAC_ENOMEM. */
+int vfx_resample_poly_f32(const float* x, unsigned long long n, const float* g, int L, int up, int down,
+                          float* y, unsigned long long ny);
 
 #ifdef __cplusplus
 }

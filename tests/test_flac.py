@@ -121,7 +121,7 @@ def test_native_library_exports_the_header(native_codec):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hdr = open(os.path.join(root, "include", "vfx_audio.h")).read()
     names = set(re.findall(r"\b(vfx_[a-z0-9_]+)\s*\(", hdr))
-    assert names == {"vfx_audio_version", "vfx_flac_decode_frames", "vfx_flac_encode_frames"}
+    assert names == {"vfx_audio_version", "vfx_flac_decode_frames", "vfx_flac_encode_frames", "vfx_resample_poly_f32"}
     for n in names:
         getattr(native_codec, n)              # AttributeError == header / library mismatch
 
@@ -355,3 +355,17 @@ def test_native_decoder_survives_corrupted_streams(native_codec):
         except flac.FlacError:
             rejected += 1
     assert rejected > 250          # (with the CRCs and the MD5 on, only damage past the last frame goes unnoticed)
+
+
+@pytest.mark.parametrize("sr_in", [48000, 16000, 22050, 96000, 8000, 24000, 11025])
+def test_native_resampler_equals_the_scipy_path(native_codec, sr_in):
+    """vfx_resample_poly_f32 (one float32 dot product per output sample) against scipy's upfirdn in float64 with the
+    same filter: same length, same alignment, float32 rounding apart -- on noise, on very short inputs and on stereo."""
+    rng = np.random.default_rng(sr_in)
+    for shape in ((1,), (7,), (1000,), (2 * sr_in + 17,), (2, 3001)):
+        x = rng.standard_normal(shape).astype(np.float32)
+        a = audio_io.resample_hq(x, sr_in, 44100, use_native=False)
+        b = audio_io.resample_hq(x, sr_in, 44100, use_native=True)
+        assert a.shape == b.shape == shape[:-1] + (-(-shape[-1] * 44100 // sr_in),) and b.dtype == np.float32
+        assert np.abs(a - b).max() < 2e-6, (shape, np.abs(a - b).max())
+    assert audio_io.resample_hq(np.zeros(0, np.float32), sr_in, 44100).shape == (0,)

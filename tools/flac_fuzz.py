@@ -60,7 +60,8 @@ def main():
             shutil.copy(os.path.join(ROOT, "voicefixer_amd", f), pkg)
         open(os.path.join(pkg, "__init__.py"), "w").close()
         subprocess.check_call(["gcc", "-O1", "-g", "-std=c11", "-fPIC", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
-                               "-shared", os.path.join(ROOT, "voicefixer_amd", "csrc_host", "vfx_flac.c"), "-lm", "-o",
+                               "-shared", os.path.join(ROOT, "voicefixer_amd", "csrc_host", "vfx_flac.c"),
+                               os.path.join(ROOT, "voicefixer_amd", "csrc_host", "vfx_resample.c"), "-lm", "-o",
                                os.path.join(pkg, "libvfx_audio.so")])
         asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
         env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0", VFX_FUZZ_PACKAGE_ROOT=tmp)

@@ -75,6 +75,9 @@ def native():
             h.vfx_flac_encode_frames.restype = ctypes.c_longlong
             h.vfx_flac_encode_frames.argtypes = [i32p, ull, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ull,
                                                  ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+            f32p = ctypes.POINTER(ctypes.c_float)
+            h.vfx_resample_poly_f32.restype = ctypes.c_int      # (audio_io.resample_hq; same library)
+            h.vfx_resample_poly_f32.argtypes = [f32p, ull, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, ull]
             if h.vfx_audio_version() >= 100:
                 _NATIVE = h
     return _NATIVE or None
