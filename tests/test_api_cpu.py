@@ -315,3 +315,51 @@ def test_model_attribute_is_a_module_handle():
     with pytest.raises(NotImplementedError):
         vf._model(None, torch.zeros(1, 1, 4, 128))
     assert vf.eval() is vf and not vf._model.training
+
+
+def test_restore_folder_host_pipeline_with_a_stub_device(tmp_path):
+    """The folder driver's host side alone (header lengths -> length-sorted windows -> decode / resample / down-mix in
+    the pool -> batches -> encode in the pool), with the device stage replaced by the identity: mixed WAV / FLAC inputs
+    at three sample rates, mono and stereo, come out under their own names, in their own container, at 44.1 kHz with
+    the lengths the header-only planner predicted."""
+    from scipy.io import wavfile
+    from voicefixer_amd import flac
+    from voicefixer_amd.api import VoiceFixer
+    rng = np.random.default_rng(0)
+    ind, outd = tmp_path / "in", tmp_path / "out"
+    ind.mkdir()
+    spec = {"a.wav": (44100, 5000, 1), "b.wav": (48000, 7001, 2), "c.flac": (16000, 3000, 1), "d.flac": (44100, 4100, 2),
+            "e.txt": None}
+    for name, sp in spec.items():
+        if sp is None:
+            (ind / name).write_text("not audio")
+            continue
+        sr, n, ch = sp
+        x = (3000 * np.sin(np.arange(n)[:, None] * 0.03 * (1 + np.arange(ch))) + rng.integers(-50, 50, (n, ch))).astype(np.int16)
+        if name.endswith(".wav"):
+            wavfile.write(str(ind / name), sr, x if ch > 1 else x[:, 0])
+        else:
+            flac.write(str(ind / name), x, sr, 16)
+    seen = []
+
+    class Stub(VoiceFixer):
+        def __init__(self):        # no checkpoints, no device: only the host logic of the class is under test
+            pass
+
+        def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, mode=0):
+            seen.append([len(w) for w in wavs])
+            return [np.asarray(w, dtype=np.float32)[None] for w in wavs]
+
+    vf = Stub()
+    assert vf.restore_folder(str(ind), str(outd), batch_size=2) == ["a.wav", "b.wav"]          # the reference's filter
+    names = vf.restore_folder(str(ind), str(outd), batch_size=2, extensions=(".wav", ".flac"), name_suffix="-mode0")
+    assert names == ["a-mode0.wav", "b-mode0.wav", "c-mode0.flac", "d-mode0.flac"]
+    want = {"a": 5000, "b": -(-7001 * 44100 // 48000), "c": -(-3000 * 44100 // 16000), "d": 4100}
+    assert seen[-1] == sorted(want.values())                    # one window, ascending lengths (what the ragged planner wants)
+    for nm in names:
+        p = str(outd / nm)
+        assert audio_io.wav_length(p) == want[nm[0]]
+        y = audio_io.load_wav(p)
+        assert y.shape == (want[nm[0]],) and np.abs(y).max() > 0.05
+    a_in = audio_io.load_wav(str(ind / "a.wav"))
+    assert np.abs(audio_io.load_wav(str(outd / "a-mode0.wav")) - a_in).max() <= 1.0 / 32768     # identity through PCM16

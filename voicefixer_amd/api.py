@@ -467,17 +467,20 @@ class VoiceFixer(nn.Module):
         return out[:, :n_out]
 
     def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None,
-                       name_suffix=""):
+                       name_suffix="", extensions=(".wav",)):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
         ``infolder`` -> same file name in ``outfolder``), batched and pipelined: the lengths come from the WAV headers,
         the length-sorted list is cut into windows of 8 batches, and while window k is restored on the device (ragged
         batches of up to ``batch_size`` files, see restore_batch) a thread pool decodes / resamples / down-mixes window k+1 and encodes
         window k-1 to PCM16.  Host memory holds two windows at most.  ``mode`` 0 or 1 (restore_batch); ``name_suffix``
-        goes between base name and extension (the CLI's ``-mode<k>`` naming for ``--mode all``).  Returns the list of
-        file names written."""
+        goes between base name and extension (the CLI's ``-mode<k>`` naming for ``--mode all``).  ``extensions``: which
+        files of the folder are taken -- the reference's loop takes ``.wav`` only (the default, and what the CLI passes);
+        ``(".wav", ".flac")`` adds FLAC inputs, written back as FLAC (the workers decode / resample / encode in
+        libvfx_audio.so, several thousand x real time, so FLAC and 48 kHz folders run at the device's rate too).
+        Returns the list of file names written."""
         from concurrent.futures import ThreadPoolExecutor
         self._check_mode(mode)
-        files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] == ".wav")
+        files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] in tuple(extensions))
         os.makedirs(outfolder, exist_ok=True)
         paths = [os.path.join(infolder, f) for f in files]
         names = [("%s%s%s" % (os.path.splitext(f)[0], name_suffix, os.path.splitext(f)[1])) for f in files]
