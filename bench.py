@@ -553,6 +553,9 @@ def main():
         "value": round(value, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
+        "value_definition": ("whole-job audio seconds per wall second with the inputs resident in HBM when the timed region "
+                             "starts and the outputs left there (the bench contract); value_host_to_host = the same from "
+                             "pinned host waveforms to pinned host waveforms, H2D / D2H inside the timed region (SURVEY.md 8(d))"),
         "config": {"workload": "batched folder restore (BASELINE configs[2]): one batch of %d x %.0f s 44.1 kHz "
                                "utterances per step, VoiceFixer.restore mode 0, seeded random weights"
                                % (args.batch, args.seconds),
