@@ -236,6 +236,115 @@ def scatter_job(args, pipe, n, rank, world, dev, dist):
     dist.destroy_process_group()
 
 
+def folder_job(args, rank, world, dev, dist):
+    """BASELINE configs[2] / [3] as the PRODUCT runs them, disk to disk: a folder of ``--synth-folder`` x world synthetic
+    utterances (PCM16 WAV on tmpfs; or ``--folder DIR``) goes through ``VoiceFixer.restore_folder`` -- every rank lists
+    the folder, takes the files dist.deal_files deals it, decodes / restores / encodes them (ragged batches of
+    ``--batch``) and writes its outputs; no data-path collective, one all-gather of per-rank counters.  Timed from the
+    folder on disk to the last output file closed, barrier + max over ranks; beside it, in the same process, the
+    HBM-resident rate of the headline bench (``hbm_resident``) so that the two can be divided."""
+    import shutil
+    import numpy as np
+    from voicefixer_amd import weights, audio_io, dist as vdist
+    from voicefixer_amd.api import VoiceFixer
+    n = int(round(args.seconds * SR))
+    tag = os.environ.get("MASTER_PORT", str(os.getpid()))
+    base = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", "vfx_bench_folder_%s" % tag)
+    ind, outd, warm_in, warm_out = (os.path.join(base, d) for d in ("in", "out", "warm_in", "warm_out"))
+    synthetic = not args.folder
+    if rank == 0:
+        shutil.rmtree(base, ignore_errors=True)
+        os.makedirs(warm_in)
+        t0 = time.perf_counter()
+        if synthetic:
+            os.makedirs(ind)
+            n_files = args.synth_folder * world
+            for i0 in range(0, n_files, 32):
+                w = synth_batch(min(32, n_files - i0), n, 3000 + i0, "cpu").numpy()
+                for r in range(w.shape[0]):
+                    audio_io.save_wave(w[r:r + 1], os.path.join(ind, "utt%05d.wav" % (i0 + r)))
+        w = synth_batch(min(args.batch, 32), n, 99, "cpu").numpy()      # warm-up folder: one batch per rank
+        for r in range(w.shape[0] * world):
+            audio_io.save_wave(w[r % w.shape[0]:r % w.shape[0] + 1], os.path.join(warm_in, "w%04d.wav" % r))
+        print("bench.py: folder prepared in %.1f s under %s" % (time.perf_counter() - t0, base), file=sys.stderr, flush=True)
+    if args.folder:
+        ind = args.folder
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    vf = VoiceFixer.from_state(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321))
+    pipe = vf._get_pipe()
+    barrier()      # (rank 0 has written the folders)
+    ext = (".wav", ".flac") if args.folder else (".wav",)
+    vf.restore_folder(warm_in, warm_out, batch_size=args.batch, io_threads=args.io_threads, rank=rank, world=world, extensions=ext)
+    barrier()
+    st = {}
+    t0 = time.perf_counter()
+    vf.restore_folder(ind, outd, batch_size=args.batch, io_threads=args.io_threads, rank=rank, world=world, stats=st,
+                      streams=args.folder_streams, extensions=ext)
+    barrier()
+    dt = time.perf_counter() - t0
+    # the HBM-resident rate of the same build in the same process (one stream, no per-launch events): bench.py's headline loop
+    x = synth_batch(args.batch, n, 1000 + rank, dev)
+    pipe.restore(x, n)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(max(2, args.steps)):
+        pipe.restore(x, n)
+    torch.cuda.synchronize()
+    hbm_ms = (time.perf_counter() - t1) / max(2, args.steps) * 1e3
+    pipe.check()
+    keys = ["files", "audio_s", "wall_s", "decode_worker_s", "encode_worker_s", "device_waited_for_decode_s", "batches"]
+    allr = vdist.gather_counters([st[k] for k in keys] + [dt, hbm_ms, float(dev.index)], dev if dist is not None else None)
+    if rank == 0:
+        outs = sorted(os.listdir(outd))
+        assert len(outs) == int(sum(x[0] for x in allr)) == st["folder_files"], (len(outs), st["folder_files"])
+        y = audio_io.load_wav(os.path.join(outd, outs[-1]))
+        assert np.isfinite(y).all() and np.abs(y).max() > 1e-3
+        dmax = max(x[7] for x in allr)
+        audio = sum(x[1] for x in allr)
+        hbm_value = world * args.batch * args.seconds / (max(x[8] for x in allr) * 1e-3)
+        line = {
+            "metric": "seconds-of-44.1kHz-audio restored per wall-second",
+            "value": round(audio / dmax, 2), "unit": "x real-time", "n_gpus": world,
+            "steps": int(max(x[6] for x in allr)), "warmup": 1, "ms_per_step": round(dmax * 1e3 / max(1, max(x[6] for x in allr)), 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic" if synthetic else "folder",
+            "value_definition": "DISK TO DISK: from the folder of PCM16 files on tmpfs to the last restored file written "
+                                "(decode, H2D, restore, D2H, int16 encode all inside the timed region); hbm_resident = the "
+                                "headline bench loop (inputs resident in HBM) in the same process, for the ratio",
+            "config": {"workload": "batched folder restore, disk to disk (BASELINE configs[%d]): %d files of %.0f s, %d per GPU, "
+                                   "ragged batches of %d, VoiceFixer.restore_folder mode 0, seeded random weights"
+                                   % (3 if world > 1 else 2, int(sum(x[0] for x in allr)), args.seconds, int(allr[0][0]), args.batch),
+                       "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "io_threads": args.io_threads,
+                       "streams": args.folder_streams, "host_cores": os.cpu_count(), "folder": base if synthetic else args.folder,
+                       "parallelism": "files dealt to %d rank(s) by dist.deal_files (no data-path collective; one all-gather of counters)" % world},
+            "hbm_resident": {"value": round(hbm_value, 2), "ms_per_step": round(max(x[8] for x in allr), 3)},
+            "disk_to_disk_over_hbm_resident": round(audio / dmax / hbm_value, 4),
+            "decode_worker_s": round(sum(x[3] for x in allr), 3), "encode_worker_s": round(sum(x[4] for x in allr), 3),
+            "decode_x_realtime_per_thread": round(audio / max(sum(x[3] for x in allr), 1e-9), 1),
+            "encode_x_realtime_per_thread": round(audio / max(sum(x[4] for x in allr), 1e-9), 1),
+            "requested_gpus": int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus)), "visible_devices": torch.cuda.device_count(),
+            "rccl": {"backend": dist.get_backend() if dist is not None else None, "world_size": world},
+            "per_rank": [{"rank": r, "device": "cuda:%d" % int(x[9]), "files": int(x[0]), "audio_s": round(x[1], 1), "batches": int(x[6]),
+                          "wall_s": round(x[7], 4), "folder_s": round(x[2], 4), "decode_worker_s": round(x[3], 3),
+                          "encode_worker_s": round(x[4], 3), "device_waited_for_decode_s": round(x[5], 4)} for r, x in enumerate(allr)],
+            "lib_build_id": _lib_build_id(),
+        }
+        _json_line_last(line)
+        shutil.rmtree(base, ignore_errors=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _lib_build_id():
+    from voicefixer_amd import _lib
+    return _lib.lib().vfx_build_id().decode()
+
+
 def _json_line_last(line):
     """Print the ONE JSON line as the last thing this job writes to stdout: librccl prints a version banner through C
     stdio (block-buffered on a pipe, so it would surface at exit, AFTER the line) -- flush that first, print, then send
@@ -253,13 +362,6 @@ def _json_line_last(line):
         pass
 
 
-def _free_port():
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        return sk.getsockname()[1]
-
-
 def self_launch(args, argv):
     """``python bench.py --gpus N`` started WITHOUT a launcher (no WORLD_SIZE): become the launcher.  One process per
     GPU under torch.distributed.run on 127.0.0.1, N clamped to the visible device count (loudly); the folder job this
@@ -272,14 +374,8 @@ def self_launch(args, argv):
               file=sys.stderr, flush=True)
     if nproc <= 1:
         return False  # fall through to the single-process path (reports n_gpus = 1, requested_gpus = N)
-    env = dict(os.environ)
-    env["VFX_BENCH_REQUESTED_GPUS"] = str(args.gpus)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (RCCL across processes on this host driver)
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // (2 * nproc))))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    sys.stdout.flush()
-    os.execve(sys.executable, cmd, env)
+    from voicefixer_amd import dist as vdist
+    vdist.exec_ranks(nproc, [os.path.abspath(__file__)] + argv, {"VFX_BENCH_REQUESTED_GPUS": str(args.gpus)})
 
 
 def dry_run(args, rank, world):
@@ -333,6 +429,12 @@ def main():
     ap.add_argument("--math", choices=["f32", "bf16x3"], default="f32",
                     help="contraction arithmetic: exact fp32 MFMA (default, the headline) or the opt-in split-bf16 "
                          "products with fp32 accumulation (DESIGN.md 3.4)")
+    ap.add_argument("--synth-folder", type=int, default=0, metavar="FILES_PER_GPU",
+                    help="BASELINE configs[2]/[3] disk to disk: FILES_PER_GPU x N synthetic --seconds utterances as PCM16 WAV on "
+                         "tmpfs through VoiceFixer.restore_folder (ranks share the folder, dist.deal_files deals the files)")
+    ap.add_argument("--folder", type=str, default="", help="the same job on an existing folder of .wav / .flac files")
+    ap.add_argument("--io-threads", type=int, default=8, help="decode / encode workers per rank of the folder job")
+    ap.add_argument("--folder-streams", type=int, default=2, help="HIP streams of the folder job's device stage")
     ap.add_argument("--dry-run", action="store_true",
                     help="test hook: rehearse the N-rank launch on CPU (gloo, no device work)")
     args = ap.parse_args()
@@ -352,7 +454,7 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device("cuda", torch.cuda.current_device())
     dist = None
-    if world > 1 or args.scatter:
+    if world > 1 or args.scatter or ((args.synth_folder or args.folder) and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -360,6 +462,8 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
+    if args.synth_folder or args.folder:
+        return folder_job(args, rank, world, dev, dist)
     from voicefixer_amd import engine, ops, weights, _lib
     build_id = _lib.lib().vfx_build_id().decode()
 

@@ -131,6 +131,13 @@ def test_stream_chunk_plan():
     assert p[-1][0] + p[-1][1] == n and p[-1][1] > ov + 1024
     with pytest.raises(ValueError):
         plan_stream_chunks(10 ** 6, 2000, 1500)
+    # mode 1: the pre-filter shortens a chunk to 512 * (len // 512) samples, so a tail of overlap + 1025 ..
+    # overlap + 1535 would arrive at the STFT with 1024 samples and raise; restore_stream asks for min_tail = 1535
+    small_ov = 100
+    n = 2 * chunk - small_ov + 1300                      # tail chunk = small_ov + 1300 samples
+    assert len(plan_stream_chunks(n, chunk, small_ov)) == 3 and len(plan_stream_chunks(n, chunk, small_ov, 1535)) == 2
+    p = plan_stream_chunks(n + 300, chunk, small_ov, 1535)  # tail = small_ov + 1600: kept, 512 * (1700 // 512) = 1536 > 1024
+    assert len(p) == 3 and 512 * (p[-1][1] // 512) > 1024
 
 
 def test_pack_direct_layout():
@@ -346,16 +353,17 @@ def test_restore_folder_host_pipeline_with_a_stub_device(tmp_path):
         def __init__(self):        # no checkpoints, no device: only the host logic of the class is under test
             pass
 
-        def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, mode=0):
-            seen.append([len(w) for w in wavs])
-            return [np.asarray(w, dtype=np.float32)[None] for w in wavs]
+        def restore_batches(self, batches, your_vocoder_func=None, streams=2, mode=0):     # the device stage
+            for tag, kind, host, lens in batches:
+                seen.append(list(lens))
+                yield tag, host.clone(), list(lens)
 
     vf = Stub()
     assert vf.restore_folder(str(ind), str(outd), batch_size=2) == ["a.wav", "b.wav"]          # the reference's filter
     names = vf.restore_folder(str(ind), str(outd), batch_size=2, extensions=(".wav", ".flac"), name_suffix="-mode0")
     assert names == ["a-mode0.wav", "b-mode0.wav", "c-mode0.flac", "d-mode0.flac"]
     want = {"a": 5000, "b": -(-7001 * 44100 // 48000), "c": -(-3000 * 44100 // 16000), "d": 4100}
-    assert seen[-1] == sorted(want.values())                    # one window, ascending lengths (what the ragged planner wants)
+    assert [n for b in seen[-2:] for n in b] == sorted(want.values())     # ascending lengths (what the ragged planner wants), batches of 2
     for nm in names:
         p = str(outd / nm)
         assert audio_io.wav_length(p) == want[nm[0]]

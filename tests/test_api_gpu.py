@@ -661,7 +661,7 @@ def test_restore_stream_mode1(vf):
     wav = (0.05 * rng.standard_normal(n) + 0.3 * np.sin(2 * np.pi * 250 * t)).astype(np.float32)
     chunk, ov = 88200 - 88200 % 512, 11025
     out = vf.restore_stream(wav, chunk_seconds=2.0, overlap_seconds=0.25, batch_size=2, mode=1)
-    plan = plan_stream_chunks(n, chunk, ov)
+    plan = plan_stream_chunks(n, chunk, ov, 1535)
     a_last, l_last = plan[-1]
     assert out.shape == (1, a_last + 512 * (l_last // 512))
     singles = [vf.restore_inmem(wav[a:a + l], cuda=True, mode=1) for a, l in plan]
@@ -722,3 +722,99 @@ def test_folder_with_a_24bit_wav(vf, tmp_path):
         f.write(b"data" + struct.pack("<I", len(raw)) + raw)
     assert vf.restore_folder(str(ind), str(outd), batch_size=4, io_threads=2) == ["a.wav", "b.wav"]
     assert audio_io.wav_length(str(outd / "b.wav")) == 26000
+
+
+def test_gru_retry_with_graphs_enabled_runs_eager(vf):
+    """with enable_graphs() the re-run after a missed GRU hand-off used to REPLAY the captured graph (two-CU
+    kernel baked in), and a shape first seen during a re-run was captured with the one-workgroup kernel for good.  Now
+    the replay path is bypassed while ``gru_single`` is set: the re-run is eager, nothing is captured in that state."""
+    gg = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    pipe = vf._get_pipe()
+    pipe.enable_graphs(max_shapes=2, max_batch=1)
+    try:
+        # (a) the shape is captured; a call that ends with the flag raised must re-run EAGERLY (a whole pass of launches),
+        # not replay the graph with the two-CU kernel baked in
+        vf.restore_inmem(gg["wav"], cuda=True)
+        assert len(pipe._graphs) == 1
+        before = _lib.lib().vfx_launch_count()
+        vf.restore_inmem(gg["wav"], cuda=True)
+        replay_launches = _lib.lib().vfx_launch_count() - before
+        retries = getattr(pipe, "gru_retries", 0)
+        pipe.restorer.gru_err.fill_(1)             # what a missed hand-off inside the replayed graph leaves behind
+        before = _lib.lib().vfx_launch_count()
+        out = vf.restore_inmem(gg["wav"], cuda=True)
+        assert pipe.gru_retries == retries + 1 and not pipe.restorer.gru_single
+        assert _rms(out, gg["restored"]) < 2e-5
+        assert _lib.lib().vfx_launch_count() - before >= replay_launches + 250
+        # (b) the entry is untouched and serves the next call
+        assert len(pipe._graphs) == 1
+        again = vf.restore_inmem(gg["wav"], cuda=True)
+        assert pipe.gru_retries == retries + 1 and _rms(again, gg["restored"]) < 2e-5
+        # (c) a shape FIRST seen during a re-run is not captured
+        pipe.restorer.gru_single = True
+        try:
+            n_graphs = len(pipe._graphs)
+            pipe.restore(torch.from_numpy(gg["wav"][None, :20000]).cuda(), 20000)
+            assert len(pipe._graphs) == n_graphs
+        finally:
+            pipe.restorer.gru_single = False
+    finally:
+        pipe.disable_graphs()
+    assert int(pipe.restorer.gru_err.item()) == 0
+
+
+def test_restore_batches_generator_order_and_gru_miss(vf):
+    """The streaming device stage: results come back in submission order with the submitted tags, whatever stream a batch
+    ran on; a missed GRU hand-off anywhere among the batches in flight re-issues all of them on the one-workgroup
+    kernel; an abandoned generator leaves the pipeline in its single-stream state."""
+    pipe = vf._get_pipe()
+    rng = np.random.default_rng(37)
+    lens = [[20000, 21000], [30000, 25000, 28000], [16000], [22050, 22050]]
+    items, want = [], []
+    for k, ls in enumerate(lens):
+        host = torch.zeros((len(ls), max(ls)), dtype=torch.float32, pin_memory=True)
+        for r, n in enumerate(ls):
+            host[r, :n] = torch.from_numpy((0.1 * rng.standard_normal(n)).astype(np.float32))
+        items.append(("tag%d" % k, "ragged", host, ls))
+        want.append([vf.restore_inmem(host[r, :n].numpy(), cuda=True) for r, n in enumerate(ls)])
+
+    def check(results):
+        assert [t for t, _, _ in results] == ["tag%d" % k for k in range(len(lens))]
+        for (tag, out_host, lens_out), ls, w in zip(results, lens, want):
+            assert list(lens_out) == ls and out_host.is_pinned()
+            for r, n in enumerate(ls):
+                assert _rms(out_host[r, :n].numpy(), w[r][0]) < 2e-5
+
+    check(list(vf.restore_batches(iter(items), streams=2)))
+    retries = getattr(pipe, "gru_retries", 0)
+    pipe.restorer._force_gru_miss = 1
+    check(list(vf.restore_batches(iter(items), streams=2)))
+    assert pipe.gru_retries == retries + 1 and int(pipe.restorer.gru_err.item()) == 0 and not pipe.restorer.gru_single
+    gen = vf.restore_batches(iter(items), streams=2)
+    next(gen)
+    gen.close()
+    assert getattr(pipe, "_n_streams", 1) == 1 and int(pipe.restorer.gru_err.item()) == 0
+    check(list(vf.restore_batches(iter(items), streams=1)))
+
+
+def test_restore_folder_two_ranks_in_one_process_equal_the_unsharded_folder(vf, tmp_path):
+    """rank= / world= on the real device path: the two halves dist.deal_files deals are disjoint, cover the folder, and every
+    file equals (to one PCM16 step: other batch shapes) what the unsharded folder run writes; counters add up."""
+    from scipy.io import wavfile
+    rng = np.random.default_rng(43)
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for k in range(7):
+        n = int(rng.integers(12000, 40000))
+        audio_io.save_wave((0.2 * rng.standard_normal(n)).astype(np.float32)[None], str(ind / ("f%d.wav" % k)))
+    whole = vf.restore_folder(str(ind), str(tmp_path / "whole"), batch_size=3, io_threads=2)
+    s0, s1 = {}, {}
+    a = vf.restore_folder(str(ind), str(tmp_path / "sharded"), batch_size=3, io_threads=2, rank=0, world=2, stats=s0)
+    b = vf.restore_folder(str(ind), str(tmp_path / "sharded"), batch_size=3, io_threads=2, rank=1, world=2, stats=s1)
+    assert not (set(a) & set(b)) and sorted(a + b) == whole == sorted(os.listdir(tmp_path / "sharded"))
+    assert s0["files"] + s1["files"] == 7 and abs(s0["audio_s"] - s1["audio_s"]) <= 40000 / 44100.0
+    assert s0["decode_worker_s"] > 0 and s0["encode_worker_s"] > 0 and s0["wall_s"] > 0
+    for f in whole:
+        _, x1 = wavfile.read(str(tmp_path / "whole" / f))
+        _, x2 = wavfile.read(str(tmp_path / "sharded" / f))
+        assert x1.shape == x2.shape and np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1

@@ -75,3 +75,129 @@ def test_scatter_restore_gather_world2(n_utt):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+# ---- folder inference sharded over ranks (VoiceFixer.restore_folder(rank, world), python -m voicefixer_amd --gpus N) ----
+
+def test_deal_files_balances_a_ragged_folder():
+    """dist.deal_files: longest first to the least loaded rank.  On a ragged 5..30 s folder every rank's audio seconds
+    are within 5 % of the mean (in fact within one file), an equal-length folder is dealt round-robin, every file has
+    exactly one owner and the answer depends on nothing but the lengths (every rank computes it alone)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for n_files, world in ((256, 2), (2048, 8), (37, 4), (3, 8)):
+        lens = [int(x) for x in rng.integers(5 * 44100, 30 * 44100, n_files)]
+        owner = vdist.deal_files(lens, world)
+        assert owner == vdist.deal_files(list(lens), world) and len(owner) == n_files and set(owner) <= set(range(world))
+        tot = [sum(l for l, o in zip(lens, owner) if o == r) for r in range(world)]
+        if n_files >= 4 * world:
+            assert max(tot) - min(tot) <= max(lens)
+            assert max(abs(t - sum(tot) / world) for t in tot) < 0.05 * sum(tot) / world
+    owner = vdist.deal_files([441000] * 2048, 8)
+    assert [owner.count(r) for r in range(8)] == [256] * 8 and owner[:16] == list(range(8)) * 2
+    # contiguous blocks of the length-sorted list (shard_range) would NOT balance: that is why the folder path does not use them
+    lens = sorted(int(x) for x in rng.integers(5 * 44100, 30 * 44100, 256))
+    lo, hi = vdist.shard_range(256, 0, 2)
+    assert sum(lens[lo:hi]) < 0.75 * sum(lens[hi:])
+
+
+def _make_ragged_folder(ind, n_files, seed=0):
+    import numpy as np
+    from scipy.io import wavfile
+    rng = np.random.default_rng(seed)
+    os.makedirs(ind, exist_ok=True)
+    lens = {}
+    for k in range(n_files):
+        n = int(rng.integers(5 * 441, 30 * 441))        # the 5..30 s distribution at 1/100 scale
+        name = "utt%03d.wav" % k
+        x = (2000 * np.sin(np.arange(n) * (0.01 + 0.001 * k)) + rng.integers(-20, 20, n)).astype(np.int16)
+        wavfile.write(os.path.join(ind, name), 44100, x)
+        lens[name] = n
+    return lens
+
+
+class _StubDevice:
+    """Mixed into VoiceFixer: the device stage replaced by x -> -x (no checkpoints, no device; the host side -- dealing,
+    planning, decode / encode workers, counters -- is what runs)."""
+
+    def __init__(self):
+        pass
+
+    def restore_batches(self, batches, your_vocoder_func=None, streams=2, mode=0):
+        for tag, kind, host, lens in batches:
+            yield tag, -host, list(lens)
+
+
+def _folder_worker(rank, world, port, ind, outd, q, use_cli):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    from voicefixer_amd import api
+
+    class Stub(_StubDevice, api.VoiceFixer):
+        pass
+
+    if use_cli:      # the console script as torch.distributed.run would start it on every rank
+        from voicefixer_amd import __main__ as cli
+        api.VoiceFixer = Stub
+        rc = cli.main(["-ifdr", ind, "-ofdr", outd, "--gpus", str(world), "--dist-backend", "gloo", "--batch-size", "4"])
+        q.put((rank, rc, None))
+        return
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = {}
+        names = Stub().restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st)   # rank / world from the group
+        per_rank = vdist.gather_counters([st["files"], st["audio_s"]])
+        q.put((rank, names, per_rank))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_cli", [False, True])
+def test_folder_sharded_over_two_ranks_every_file_written_once(tmp_path, use_cli):
+    """World-2 gloo run of the sharded folder job with the stub device stage: every file of a ragged folder is written
+    exactly once (the two ranks' name lists are disjoint and cover the folder), each output is ITS input through the
+    stub (so no row got mixed up in staging / batching), and the ranks' audio seconds agree within 5 %."""
+    import numpy as np
+    from voicefixer_amd import audio_io
+    ind, outd = str(tmp_path / "in"), str(tmp_path / "out")
+    lens = _make_ragged_folder(ind, 41)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_folder_worker, args=(r, 2, port, ind, outd, q, use_cli)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(os.listdir(outd)) == sorted(lens)
+    for name, n in lens.items():
+        y, x = audio_io.load_wav(os.path.join(outd, name)), audio_io.load_wav(os.path.join(ind, name))
+        assert y.shape == (n,) and np.abs(y + x).max() <= 1.0 / 32768 + 1e-7, name
+    if use_cli:
+        assert sorted(g[1] for g in got) == [0, 0]
+        return
+    a, b = (set(g[1]) for g in sorted(got))
+    assert not (a & b) and a | b == set(lens) and abs(len(a) - len(b)) <= 3
+    per_rank = got[0][2]
+    assert per_rank == got[1][2] and sum(int(x[0]) for x in per_rank) == 41
+    secs = [x[1] for x in per_rank]
+    assert abs(secs[0] - secs[1]) < 0.05 * (sum(secs) / 2)
+    assert abs(sum(secs) - sum(lens.values()) / 44100.0) < 1e-6
+
+
+def test_restore_folder_explicit_rank_and_world_without_a_process_group(tmp_path):
+    """rank= / world= given explicitly (no torch.distributed group): two calls in one process write disjoint halves."""
+    from voicefixer_amd import api
+
+    class Stub(_StubDevice, api.VoiceFixer):
+        pass
+
+    ind, outd = str(tmp_path / "in"), str(tmp_path / "out")
+    lens = _make_ragged_folder(ind, 9, seed=1)
+    a = Stub().restore_folder(ind, outd, batch_size=2, io_threads=2, rank=0, world=2)
+    assert set(os.listdir(outd)) == set(a) and 0 < len(a) < 9
+    b = Stub().restore_folder(ind, outd, batch_size=2, io_threads=2, rank=1, world=2)
+    assert not (set(a) & set(b)) and set(a) | set(b) == set(lens)
+    with pytest.raises(ValueError):
+        Stub().restore_folder(ind, outd, rank=2, world=2)

@@ -369,3 +369,48 @@ def test_native_resampler_equals_the_scipy_path(native_codec, sr_in):
         assert a.shape == b.shape == shape[:-1] + (-(-shape[-1] * 44100 // sr_in),) and b.dtype == np.float32
         assert np.abs(a - b).max() < 2e-6, (shape, np.abs(a - b).max())
     assert audio_io.resample_hq(np.zeros(0, np.float32), sr_in, 44100).shape == (0,)
+
+
+def _patched_total(data, total):
+    """The same stream with STREAMINFO's 36-bit sample count overwritten (file bytes 18..25 hold sr/ch/bps/total)."""
+    v = int.from_bytes(data[18:26], "big")
+    v = (v & ~((1 << 36) - 1)) | total
+    return data[:18] + v.to_bytes(8, "big") + data[26:]
+
+
+def test_untrusted_streaminfo_sample_count(tmp_path):
+    """the 36-bit sample count of STREAMINFO is untrusted.  A crafted count that the file's bytes cannot
+    hold raises FlacError before anything is allocated (it used to size an np.empty of up to 2^36 * channels * 4 bytes);
+    a count of ZERO (legal: streamed encoders do not know the length) still decodes, and wav_length counts the frames."""
+    rng = np.random.default_rng(5)
+    pcm = (2000 * np.sin(np.arange(9000)[:, None] * 0.01) + rng.integers(-30, 30, (9000, 1))).astype(np.int32)
+    good = flac.encode(pcm, 44100, 16)
+    for native_flag in (None, False):
+        with pytest.raises(flac.FlacError, match="cannot hold"):
+            flac.decode(_patched_total(good, (1 << 36) - 1), use_native=native_flag)
+    unknown = _patched_total(good, 0)
+    sr, got, bps = flac.decode(unknown, verify=False)
+    assert sr == 44100 and bps == 16 and np.array_equal(got, pcm)
+    p = str(tmp_path / "stream.flac")
+    open(p, "wb").write(unknown)
+    assert flac.info(p)[3] == 0 and audio_io.wav_length(p) == 9000 == len(audio_io.load_wav(p))
+
+
+def test_native_handle_is_published_once_to_racing_threads(native_codec):
+    """restore_folder's decode workers are the first callers of flac.native(), all at once; every one of
+    them must get the C library (the loader used to publish ``False`` first, and racing threads fell back to the
+    Python codec)."""
+    import threading
+    flac._NATIVE = None
+    seen, gate = [], threading.Barrier(8)
+
+    def worker():
+        gate.wait()
+        seen.append(flac.native())
+
+    ts = [threading.Thread(target=worker) for _ in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert len(seen) == 8 and all(h is not None and h is seen[0] for h in seen)

@@ -11,6 +11,10 @@ Differences, all deliberate:
   * mode 2 (train-mode BatchNorm + Dropout) is not built: ``--mode 2`` raises NotImplementedError, ``--mode all`` writes
     modes 0 and 1 and says that mode 2 was skipped;
   * ``--weight_prepare`` cannot download (no network): it only reports whether both checkpoints are in place;
+  * ``--gpus N`` (extension, folder mode): the folder is sharded over N MI355X, one process per GPU -- the command
+    re-executes itself under ``torch.distributed.run`` on 127.0.0.1 (N clamped, loudly, to the visible devices), every
+    rank lists the folder, takes the files ``dist.deal_files`` deals it and writes their outputs; the only collective is
+    one all-gather of per-rank counters at the end (RCCL);
   * output formats are WAV and FLAC (``audio_io.FORMATS``) instead of whatever libsndfile offers.
 """
 import argparse
@@ -84,10 +88,42 @@ def build_parser():
     parser.add_argument("--weight_prepare", default=False, action="store_true",
                         help="Only check that both checkpoints are in place (no network here: nothing is downloaded).")
     parser.add_argument("--batch-size", type=int, default=32, help="(extension) files per ragged batch in folder mode")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="(extension) folder mode: shard the folder over this many GPUs (one process per GPU, self-launched)")
+    parser.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                        help="(extension) torch.distributed backend of the per-rank counter exchange (nccl == RCCL)")
     return parser
 
 
+def folder_ranks(args, argv):
+    """``--gpus N`` given to a PLAIN invocation (no WORLD_SIZE): re-execute under torch.distributed.run, one rank per
+    visible device (at most N).  Returns only when a single process is what should run."""
+    import torch
+    from . import dist as vdist
+    visible = torch.cuda.device_count()
+    nproc = max(1, min(args.gpus, visible))
+    if nproc < args.gpus:
+        print("voicefixer_amd: WARNING: --gpus %d requested but only %d HIP device(s) visible -> %d rank(s)"
+              % (args.gpus, visible, nproc), file=sys.stderr, flush=True)
+    if nproc > 1:
+        vdist.exec_ranks(nproc, ["-m", "voicefixer_amd"] + list(argv))
+
+
+def report_ranks(per_rank, silent):
+    """Rank 0's summary of a sharded folder job (what every rank's ``stats`` dict held, all-gathered)."""
+    if silent:
+        return
+    for r, (files, audio_s, wall_s, dec, enc, stall) in enumerate(per_rank):
+        print("rank %d: %d files, %.1f s of audio in %.2f s (%.0fx real time); decode %.2f / encode %.2f worker-seconds, "
+              "device waited %.2f s for input" % (r, files, audio_s, wall_s, audio_s / max(wall_s, 1e-9), dec, enc, stall))
+    wall = max(x[2] for x in per_rank)
+    total = sum(x[1] for x in per_rank)
+    print("whole job: %d files, %.1f s of audio in %.2f s = %.0fx real time on %d GPU(s)"
+          % (sum(int(x[0]) for x in per_rank), total, wall, total / max(wall, 1e-9), len(per_rank)))
+
+
 def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
     args = build_parser().parse_args(argv)
     if args.weight_prepare:
         from . import api
@@ -106,11 +142,24 @@ def main(argv=None):
         raise NotImplementedError("mode 2 (train-mode BatchNorm + Dropout, voicefixer/base.py:114-115) is nondeterministic "
                                   "and not built in voicefixer_amd; modes 0 and 1 are")
     import torch
-    from .api import VoiceFixer
+    from . import api
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and process_folder and "WORLD_SIZE" not in os.environ:
+        folder_ranks(args, argv)      # does not return when it re-executes under torch.distributed.run
+    rank = 0
+    if world > 1:
+        import torch.distributed as tdist
+        rank = int(os.environ.get("RANK", "0"))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+        tdist.init_process_group(backend=args.dist_backend)
+        if rank != 0:
+            args.silent = True        # rank 0 speaks for the job
+            process_file = False      # a single file is one rank's work
     cuda = bool(torch.cuda.is_available() and not args.disable_cuda)
     if not args.silent:
         print("Initializing VoiceFixer")
-    voicefixer = VoiceFixer()
+    voicefixer = api.VoiceFixer()
     if not args.silent:
         print("Start processing the input file %s." % args.infile)
     modes = list(MODES_BUILT) if args.mode == "all" else [int(args.mode)]
@@ -124,12 +173,24 @@ def main(argv=None):
         n_files = len([f for f in os.listdir(args.infolder) if os.path.splitext(os.path.basename(f))[-1] == ".wav"])
         if not args.silent:
             print("Found %s .wav files in the input folder %s. Start processing." % (n_files, args.infolder))
+        from . import dist as vdist
         for m in modes:
             start = time.time()
+            st = {}
             voicefixer.restore_folder(args.infolder, args.outfolder, mode=m, batch_size=args.batch_size,
-                                      name_suffix="-mode%d" % m if append else "")
+                                      name_suffix="-mode%d" % m if append else "", stats=st)
+            if world > 1:
+                dev = torch.device("cuda", torch.cuda.current_device()) if args.dist_backend == "nccl" else None
+                per_rank = vdist.gather_counters([st["files"], st["audio_s"], st["wall_s"], st["decode_worker_s"],
+                                                  st["encode_worker_s"], st["device_waited_for_decode_s"]], dev)
+                if rank == 0:
+                    report_ranks(per_rank, args.silent)
             if not args.silent:
                 print("Restoration of %d files (mode %d) took %s s" % (n_files, m, round(time.time() - start, 1)))
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
     if not args.silent:
         print("Done")
     return 0

@@ -79,10 +79,11 @@ def plan_batches(sorted_lengths, batch_size, ragged_ratio=0.5, ragged=True):
     return plan
 
 
-def plan_stream_chunks(n, chunk, overlap):
+def plan_stream_chunks(n, chunk, overlap, min_tail=1024):
     """Chunk starts / lengths of the overlap-add streaming mode: chunks of ``chunk`` samples every
     ``chunk - overlap`` samples; the last one is shorter.  A tail that would be too short to restore
-    (<= overlap + 1024 samples: one cross-fade plus the reflect pad of the STFT) is merged into its predecessor."""
+    (<= overlap + ``min_tail`` samples: one cross-fade plus the reflect pad of the STFT; mode 1 passes 1535 because its
+    pre-filter first shortens a chunk to 512 * (len // 512) samples) is merged into its predecessor."""
     if chunk <= overlap + 1024 or overlap < 0:
         raise ValueError("chunk must exceed overlap + 1024 samples")
     hop = chunk - overlap
@@ -94,7 +95,7 @@ def plan_stream_chunks(n, chunk, overlap):
         if start + length >= n:
             break
         start += hop
-    if len(plan) > 1 and plan[-1][1] <= overlap + 1024:
+    if len(plan) > 1 and plan[-1][1] <= overlap + min_tail:
         last = plan.pop()
         plan[-1][1] = last[0] + last[1] - plan[-1][0]
     return [tuple(c) for c in plan]
@@ -326,6 +327,130 @@ class VoiceFixer(nn.Module):
             n = seg.shape[1]
         return pipe.restore(seg, n, your_vocoder_func)
 
+    def _streams(self, streams):
+        """The SAME stream objects on every call: torch's caching allocator keeps one block pool per stream, so fresh
+        streams per call (torch hands them out round-robin from 32) would strand a batch's worth of HBM in a new pool
+        each time until the allocator has to flush everything (measured: a 5x slower call after ~6 calls)."""
+        pipe = self._get_pipe()
+        if not hasattr(self, "_stream_pool"):
+            self._stream_pool = []
+        while len(self._stream_pool) < max(1, int(streams)):
+            self._stream_pool.append(torch.cuda.Stream(device=pipe.device))
+        return self._stream_pool[:max(1, int(streams))]
+
+    def _issue_batch(self, pipe, stream, item, mode, your_vocoder_func):
+        """Queue ONE batch on ``stream``: H2D of its pinned staging tensor, the launch sequence, D2H of the result into
+        a pinned tensor, an event.  Nothing here waits for the device."""
+        from . import ops
+        tag, kind, host, lens = item
+        lens = list(lens)
+        with torch.cuda.stream(stream):
+            seg = host.to(pipe.device, non_blocking=True)
+            if kind == "ragged":
+                if mode == 1:
+                    if min(lens) < 1536:
+                        raise VfxError("mode 1 shortens a file to 512 * (n // 512) samples: %d samples leave too few for the "
+                                       "reflect-padded STFT (needs > 1024 after the cut)" % min(lens))
+                    cut = torch.zeros_like(seg)
+                    done = {}
+                    for r in range(len(lens)):           # the cut-off is a per-file quantity (base.py:87-104);
+                        if r in done:                    # rows of EQUAL length share one launch (vfx_hf_cut_f32 takes B rows)
+                            continue
+                        same = [q for q in range(r, len(lens)) if lens[q] == lens[r]]
+                        if same == list(range(r, r + len(same))):
+                            y, _ = ops.hf_cut(seg[r:r + len(same), :lens[r]], lens[r], 0.95)
+                            cut[r:r + len(same), :y.shape[1]] = y
+                        else:
+                            for q in same:
+                                y, _ = ops.hf_cut(seg[q:q + 1, :lens[q]], lens[q], 0.95)
+                                cut[q, :y.shape[1]] = y[0]
+                        for q in same:
+                            done[q] = True
+                    lens = [512 * (n // 512) for n in lens]
+                    seg = cut[:, :max(lens)].contiguous()
+                full = pipe.restore_rows(seg, lens)
+                lens_out = lens
+            else:
+                n = lens[0]
+                parts = [self._restore_segments(pipe, seg[:, s0:s0 + SEG_LENGTH], min(SEG_LENGTH, n - s0), mode,
+                                                your_vocoder_func) for s0 in range(0, n, SEG_LENGTH)]
+                full = parts[0] if len(parts) == 1 else torch.cat(parts, -1)
+                lens_out = [full.shape[-1]] * len(lens)
+            out_host = torch.empty(tuple(full.shape), dtype=torch.float32, pin_memory=True)
+            out_host.copy_(full, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        return [item, out_host, lens_out, ev]
+
+    @torch.no_grad()
+    def restore_batches(self, batches, your_vocoder_func=None, streams=2, mode=0):
+        """The device stage of folder inference as a GENERATOR: ``batches`` yields ``(tag, kind, host, lens)`` --
+        ``host`` a pinned float32 (B, >= max(lens)) staging tensor whose row r holds ``lens[r]`` samples, ``kind``
+        "ragged" (one launch sequence with per-row lengths, Pipeline.restore_rows) or "samples" (equal lengths: files
+        of several 30 s segments, plugin vocoders) as ``plan_batches`` cuts them -- and the generator yields
+        ``(tag, out_host, lens_out)`` in the same order, ``out_host`` a pinned (B, >= max(lens_out)) tensor.
+        Batches go round-robin to ``streams`` HIP streams (the low-occupancy phases of one batch -- GRU recurrence, deep
+        UNet levels -- overlap the convolutions of the next) and the host runs one batch per stream AHEAD of the device:
+        H2D, the ~600 launches and the D2H of a batch are queued while earlier batches compute, so the device never waits
+        for the host and the caller (restore_folder: decode / encode workers) works on other batches meanwhile.
+        The two-CU GRU's error flag is read when a batch's result crosses to the host; a missed hand-off drains the
+        batches in flight and re-issues them on the one-workgroup GRU kernel (Pipeline.run_checked's rule)."""
+        from collections import deque
+        from .engine import GruHandoffMissed
+        self._check_mode(mode)
+        pipe = self._get_pipe()
+        pool = self._streams(streams)
+        main = torch.cuda.current_stream(pipe.device)
+        for st in pool:
+            st.wait_stream(main)
+        inflight = deque()
+        pipe.set_streams(len(pool))
+        ok = False
+        try:
+            pipe.check()                      # a flag that is already set belongs to an earlier, unchecked launch
+            nb = 0
+
+            def finish_oldest():
+                rec = inflight[0]
+                rec[3].synchronize()
+                try:
+                    pipe.check()
+                except GruHandoffMissed:
+                    # which of the batches in flight raised it cannot be told: drain them all, re-issue every one of
+                    # them with the recurrences on vfx_gru_bidir_f32 (nothing to miss), one after the other
+                    torch.cuda.synchronize(pipe.device)
+                    pipe.restorer.gru_err.zero_()
+                    pipe.restorer.gru_single = True
+                    try:
+                        for q in range(len(inflight)):
+                            inflight[q] = self._issue_batch(pipe, pool[0], inflight[q][0], mode, your_vocoder_func)
+                        torch.cuda.synchronize(pipe.device)
+                        pipe.check()
+                    finally:
+                        pipe.restorer.gru_single = False
+                    pipe.gru_retries = getattr(pipe, "gru_retries", 0) + 1
+                    rec = inflight[0]
+                inflight.popleft()
+                return rec[0][0], rec[1], rec[2]
+
+            for item in batches:
+                inflight.append(self._issue_batch(pipe, pool[nb % len(pool)], item, mode, your_vocoder_func))
+                nb += 1
+                while len(inflight) > len(pool) + 1:
+                    yield finish_oldest()
+            while inflight:
+                yield finish_oldest()
+            ok = True
+        finally:
+            # in every case: drain the side streams and give the GRU its single-stream launch size back; when a batch
+            # raised (a too-short file, an out-of-memory, a plugin vocoder error) or the caller abandoned the
+            # generator, whatever the queued launches leave in the device-side error flag belongs to THIS call -- drop
+            # it here so that a later, unrelated call does not inherit it
+            torch.cuda.synchronize(pipe.device)
+            pipe.set_streams(1)
+            if not ok and pipe.restorer.gru_err is not None:
+                pipe.restorer.gru_err.zero_()
+
     @torch.no_grad()
     def restore_batch(self, wavs, your_vocoder_func=None, batch_size=32, streams=2, ragged_ratio=0.5, mode=0):
         """Batched folder inference (not in the reference, which loops files at B=1,
@@ -336,86 +461,32 @@ class VoiceFixer(nn.Module):
         is ONE launch sequence in which every kernel takes the per-row lengths (Pipeline.restore_rows) -- each row is
         what restoring that utterance alone returns, the tiles past a row's end are skipped, only the buffers are
         sized for the longest row.  Longer files (several 30 s segments) and plugin vocoders are bucketed by exact
-        length, one batched launch sequence per segment index.  Batches go round-robin to ``streams`` HIP streams: the
-        low-occupancy phases of one batch (GRU recurrence, deep UNet levels) overlap the convolutions of the next.
+        length, one batched launch sequence per segment index.  The batches run through ``restore_batches`` (round-robin
+        on ``streams`` HIP streams, pinned staging in both directions, the host one batch per stream ahead).
         ``mode=1``: every file (every 30 s segment of it) first goes through the device-side high-frequency cut
         (base.py:121-122, ``vfx_hf_cut_f32``) exactly as ``restore_inmem(mode=1)`` does it."""
-        from . import ops
         self._check_mode(mode)
-        pipe = self._get_pipe()
         order = sorted(range(len(wavs)), key=lambda i: len(wavs[i]))
         outs = [None] * len(wavs)
-        # the SAME stream objects on every call: torch's caching allocator keeps one block pool per stream, so fresh
-        # streams per call (torch hands them out round-robin from 32) would strand a batch's worth of HBM in a new
-        # pool each time until the allocator has to flush everything (measured: a 5x slower call after ~6 calls)
-        if not hasattr(self, "_stream_pool"):
-            self._stream_pool = []
-        while len(self._stream_pool) < max(1, int(streams)):
-            self._stream_pool.append(torch.cuda.Stream(device=pipe.device))
-        pool = self._stream_pool[:max(1, int(streams))]
-        main = torch.cuda.current_stream(pipe.device)
-        for st in pool:
-            st.wait_stream(main)
+        plan = plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio, ragged=your_vocoder_func is None)
 
-        def run():
-            pending, staging = [], []
-            pipe.set_streams(len(pool))
-            try:
-                for nb, (kind, grp) in enumerate(plan_batches([len(wavs[k]) for k in order], batch_size, ragged_ratio,
-                                                             ragged=your_vocoder_func is None)):
-                    grp = [order[g] for g in grp]
-                    with torch.cuda.stream(pool[nb % len(pool)]):
-                        if kind == "ragged":
-                            lens = [len(wavs[k]) for k in grp]
-                            # rows are padded in a PINNED staging buffer (torch caches pinned blocks) and uploaded without
-                            # blocking the host, so that the next batch is staged while this one's copy and kernels run
-                            host = torch.zeros((len(grp), max(lens)), dtype=torch.float32, pin_memory=True)
-                            hv = host.numpy()
-                            for r, k in enumerate(grp):
-                                hv[r, :lens[r]] = wavs[k]
-                            seg = host.to(pipe.device, non_blocking=True)
-                            staging.append(host)    # stays alive until the device has been synchronised below
-                            if mode == 1:
-                                cut = torch.zeros_like(seg)
-                                for r in range(len(grp)):          # the cut-off is a per-file quantity (base.py:87-104)
-                                    y, _ = ops.hf_cut(seg[r:r + 1, :lens[r]], lens[r], 0.95)
-                                    lens[r] = y.shape[1]
-                                    cut[r, :lens[r]] = y[0]
-                                seg = cut[:, :max(lens)].contiguous()
-                            full = pipe.restore_rows(seg, lens)
-                            pending.append((grp, lens, full))
-                        else:
-                            n = len(wavs[grp[0]])
-                            parts = []
-                            for s0 in range(0, n, SEG_LENGTH):
-                                host = torch.from_numpy(np.stack([np.asarray(wavs[k], np.float32)[s0:s0 + SEG_LENGTH]
-                                                                  for k in grp])).pin_memory()
-                                staging.append(host)
-                                parts.append(self._restore_segments(pipe, host.to(pipe.device, non_blocking=True),
-                                                                    host.shape[1], mode, your_vocoder_func))
-                            full = torch.cat(parts, -1)
-                            pending.append((grp, [full.shape[-1]] * len(grp), full))
-            except BaseException:
-                # a batch raised (a too-short file, an out-of-memory, a plugin vocoder error): whatever the launches
-                # already queued leave in the device-side error flag belongs to THIS call -- drop it here so that a
-                # later, unrelated call does not inherit it
-                torch.cuda.synchronize(pipe.device)
-                if pipe.restorer.gru_err is not None:
-                    pipe.restorer.gru_err.zero_()
-                raise
-            finally:
-                # in every case: drain the side streams before the staging buffers go away and give the GRU its
-                # single-stream launch size back
-                torch.cuda.synchronize(pipe.device)
-                pipe.set_streams(1)
-                del staging
-            return pending
+        def staged():
+            for kind, grp in plan:
+                idx = [order[g] for g in grp]
+                lens = [len(wavs[k]) for k in idx]
+                # rows are padded in a PINNED staging buffer (torch caches pinned blocks) and uploaded without
+                # blocking the host, so that the next batch is staged while this one's copy and kernels run
+                host = torch.empty((len(idx), max(lens)), dtype=torch.float32, pin_memory=True)
+                hv = host.numpy()
+                for r, k in enumerate(idx):
+                    hv[r, :lens[r]] = wavs[k]
+                    hv[r, lens[r]:] = 0.0
+                yield idx, kind, host, lens
 
-        pending = pipe.run_checked(run)   # (reads the device error flags; a missed GRU hand-off re-runs the batches)
-        for grp, lens, full in pending:
-            full = full.cpu().numpy()
-            for r, k in enumerate(grp):
-                outs[k] = full[r:r + 1, :lens[r]]
+        for idx, out_host, lens_out in self.restore_batches(staged(), your_vocoder_func, streams, mode):
+            ov = out_host.numpy()
+            for r, k in enumerate(idx):
+                outs[k] = ov[r:r + 1, :lens_out[r]].copy()   # (the pinned block goes back to torch's host cache)
         return outs
 
     @torch.no_grad()
@@ -437,7 +508,7 @@ class VoiceFixer(nn.Module):
         chunk, ov = int(round(chunk_seconds * 44100)), int(round(overlap_seconds * 44100))
         if mode == 1:
             chunk -= chunk % 512
-        plan = plan_stream_chunks(n, chunk, ov)
+        plan = plan_stream_chunks(n, chunk, ov, 1535 if mode == 1 else 1024)
         out = np.zeros((1, n), np.float32)
         fade_in = (np.arange(ov, dtype=np.float32) / max(ov, 1))[None]
         done = 0  # output is final below this sample
@@ -467,43 +538,105 @@ class VoiceFixer(nn.Module):
         return out[:, :n_out]
 
     def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None,
-                       name_suffix="", extensions=(".wav",)):
+                       name_suffix="", extensions=(".wav",), rank=None, world=None, streams=2, ahead=3, stats=None):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
-        ``infolder`` -> same file name in ``outfolder``), batched and pipelined: the lengths come from the WAV headers,
-        the length-sorted list is cut into windows of 8 batches, and while window k is restored on the device (ragged
-        batches of up to ``batch_size`` files, see restore_batch) a thread pool decodes / resamples / down-mixes window k+1 and encodes
-        window k-1 to PCM16.  Host memory holds two windows at most.  ``mode`` 0 or 1 (restore_batch); ``name_suffix``
-        goes between base name and extension (the CLI's ``-mode<k>`` naming for ``--mode all``).  ``extensions``: which
-        files of the folder are taken -- the reference's loop takes ``.wav`` only (the default, and what the CLI passes);
-        ``(".wav", ".flac")`` adds FLAC inputs, written back as FLAC (the workers decode / resample / encode in
-        libvfx_audio.so, several thousand x real time, so FLAC and 48 kHz folders run at the device's rate too).
-        Returns the list of file names written."""
+        ``infolder`` -> same file name in ``outfolder``), batched, pipelined and -- with ``world`` > 1 -- sharded over
+        one process per GPU (BASELINE configs[2] and [3]).
+
+        Every rank lists the folder and reads the lengths from the file HEADERS (cheap, no decoding), so all ranks hold
+        the same work list without exchanging anything; ``dist.deal_files`` deals the files longest-first to the least
+        loaded rank (equal sample totals to within one file, whatever the length distribution -- NOT contiguous blocks of
+        the sorted list, which would give one rank all the long files); a rank cuts ITS files, sorted by length, into
+        ragged batches (``plan_batches``) and streams them: a thread pool decodes / resamples / down-mixes the files of
+        the next ``ahead`` batches straight into pinned staging rows, ``restore_batches`` keeps one batch per HIP stream
+        running and one more queued, and the pool encodes each finished batch to PCM16 from the pinned result --
+        decode || restore || encode with the device never waiting.  No collective in the data path; every output file is
+        written by exactly one rank.  ``rank`` / ``world`` default to the initialised ``torch.distributed`` group (or 0 / 1).
+
+        ``mode`` 0 or 1 (restore_batch); ``name_suffix`` goes between base name and extension (the CLI's ``-mode<k>``
+        naming for ``--mode all``).  ``extensions``: which files of the folder are taken -- the reference's loop takes
+        ``.wav`` only (the default, and what the CLI passes); ``(".wav", ".flac")`` adds FLAC inputs, written back as
+        FLAC (the workers decode / resample / encode in libvfx_audio.so, several thousand x real time).
+        ``stats`` (optional dict) receives this rank's counters: files, audio seconds, wall seconds, summed worker
+        seconds of decode and encode, seconds the device stage waited for decoded input.
+        Returns the list of file names THIS rank wrote."""
+        import threading
+        import time
         from concurrent.futures import ThreadPoolExecutor
+        from . import dist as vdist, flac
         self._check_mode(mode)
+        rank, world = vdist.rank_world(rank, world)
         files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] in tuple(extensions))
         os.makedirs(outfolder, exist_ok=True)
         paths = [os.path.join(infolder, f) for f in files]
         names = [("%s%s%s" % (os.path.splitext(f)[0], name_suffix, os.path.splitext(f)[1])) for f in files]
+        if any(p.lower().endswith(".flac") for p in paths):
+            flac.native()      # load the C codec once, before the workers race for it
+        t_start = time.perf_counter()
+        lock = threading.Lock()
+        cnt = {"decode_s": 0.0, "encode_s": 0.0, "stall_s": 0.0}
+
+        def decode_into(i, row, n):
+            t0 = time.perf_counter()
+            x = audio_io.load_wav(paths[i], 44100)
+            if len(x) != n:
+                raise RuntimeError("%s: header promised %d samples at 44.1 kHz, decoder returned %d" % (paths[i], n, len(x)))
+            row[:n] = x
+            row[n:] = 0.0
+            with lock:
+                cnt["decode_s"] += time.perf_counter() - t0
+
+        def encode_from(row, i):
+            t0 = time.perf_counter()
+            audio_io.save_wave(row, os.path.join(outfolder, names[i]), 44100)
+            with lock:
+                cnt["encode_s"] += time.perf_counter() - t0
+
+        written = []
         with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
-            # lengths from the headers only (cheap), so that the work list can be sorted and cut into windows before
-            # anything is decoded; then a three-stage pipeline over the windows of the length-sorted list:
-            #   decode / resample / down-mix window k+1 (pool)  ||  restore window k (device)  ||  encode window k-1 (pool)
             lengths = list(pool.map(lambda p: audio_io.wav_length(p, 44100), paths))
-            order = sorted(range(len(files)), key=lambda i: lengths[i])
-            win = max(batch_size, 1) * 8
-            windows = [order[w0:w0 + win] for w0 in range(0, len(order), win)]
-            load = lambda i: audio_io.load_wav(paths[i], 44100)
+            owner = vdist.deal_files(lengths, world)
+            mine = sorted((i for i in range(len(files)) if owner[i] == rank), key=lambda i: (lengths[i], i))
+            plan = plan_batches([lengths[i] for i in mine], batch_size, ragged=your_vocoder_func is None)
+
+            def submit_decode(b):
+                kind, grp = plan[b]
+                idx = [mine[g] for g in grp]
+                lens = [lengths[i] for i in idx]
+                host = torch.empty((len(idx), max(lens)), dtype=torch.float32, pin_memory=self._pin_memory())
+                hv = host.numpy()
+                return idx, kind, host, lens, [pool.submit(decode_into, i, hv[r], lens[r]) for r, i in enumerate(idx)]
+
+            def decoded():
+                queue = [submit_decode(b) for b in range(min(ahead, len(plan)))]
+                for b in range(len(plan)):
+                    idx, kind, host, lens, futs = queue.pop(0)
+                    if b + ahead < len(plan):
+                        queue.append(submit_decode(b + ahead))
+                    t0 = time.perf_counter()
+                    for f in futs:
+                        f.result()
+                    cnt["stall_s"] += time.perf_counter() - t0
+                    yield idx, kind, host, lens
+
             writes = []
-            pending = [pool.submit(load, i) for i in windows[0]] if windows else []
-            for k, idx in enumerate(windows):
-                wavs = [f.result() for f in pending]
-                pending = [pool.submit(load, i) for i in windows[k + 1]] if k + 1 < len(windows) else []
-                outs = self.restore_batch(wavs, your_vocoder_func, batch_size, mode=mode)
-                for i, o in zip(idx, outs):
-                    writes.append(pool.submit(audio_io.save_wave, o, os.path.join(outfolder, names[i]), 44100))
+            for idx, out_host, lens_out in self.restore_batches(decoded(), your_vocoder_func, streams, mode):
+                ov = out_host.numpy()       # (the views keep the pinned block alive until its rows are encoded)
+                for r, i in enumerate(idx):
+                    writes.append(pool.submit(encode_from, ov[r:r + 1, :lens_out[r]], i))
+                    written.append(names[i])
             for w in writes:
                 w.result()
-        return names
+        if stats is not None:
+            stats.update(rank=rank, world=world, files=len(mine), folder_files=len(files), batches=len(plan),
+                         audio_s=sum(lengths[i] for i in mine) / 44100.0, wall_s=time.perf_counter() - t_start,
+                         decode_worker_s=cnt["decode_s"], encode_worker_s=cnt["encode_s"],
+                         device_waited_for_decode_s=cnt["stall_s"], io_threads=max(1, io_threads))
+        return sorted(written)
+
+    @staticmethod
+    def _pin_memory():
+        return torch.cuda.is_available()
 
     def restore(self, input, output, cuda=False, mode=0, your_vocoder_func=None):
         wav_10k = self._load_wav(input, sample_rate=44100)

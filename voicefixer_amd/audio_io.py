@@ -81,6 +81,8 @@ def wav_length(path, sample_rate=SR):
     if str(path).lower().endswith(".flac"):
         from . import flac
         sr, _, _, n = flac.info(path)
+        if n == 0:      # legal for streamed encoders (unknown length): count what is really there
+            n = flac.read(path)[1].shape[0]
     else:
         sr, n = _riff_info(path)
     if sr == sample_rate:

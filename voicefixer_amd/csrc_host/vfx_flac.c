@@ -28,7 +28,9 @@ static uint8_t crc8_tab[256];
 static uint16_t crc16_tab[256];
 static int crc_ready = 0;
 
-static void crc_init(void) {
+/* runs when the library is loaded (before any caller's thread can reach the codec), so the entry points stay
+   re-entrant; the calls at their heads are then no-ops */
+__attribute__((constructor)) static void crc_init(void) {
     if (crc_ready) return;
     for (int i = 0; i < 256; ++i) {
         uint8_t c = (uint8_t)i;

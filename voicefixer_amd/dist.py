@@ -18,6 +18,70 @@ def shard_range(n_items, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rank_world(rank=None, world=None):
+    """(rank, world) of a sharded job: the arguments if given, else the initialised ``torch.distributed`` group, else (0, 1)."""
+    if world is None:
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+    rank = 0 if rank is None else int(rank)
+    if not 0 <= rank < int(world):
+        raise ValueError("rank %d outside world of %d" % (rank, world))
+    return rank, int(world)
+
+
+def deal_files(costs, world):
+    """Deal items with the given costs (samples of every file of a folder) to ``world`` ranks: longest first, each to
+    the rank with the smallest total so far (ties: fewer items, then lower rank).  Returns owner[i].  Every rank
+    computes the same answer from the same header lengths -- no exchange; totals differ by at most one item's cost
+    (LPT rule), so a ragged 5..30 s folder loads all ranks alike, and an equal-length folder is dealt round-robin.
+    (``shard_range`` -- contiguous blocks -- stays what the in-memory scatter uses, where all rows are equally long.)"""
+    import heapq
+    owner = [0] * len(costs)
+    heap = [(0, 0, r) for r in range(int(world))]
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        total, count, r = heapq.heappop(heap)
+        owner[i] = r
+        heapq.heappush(heap, (total + max(int(costs[i]), 0), count + 1, r))
+    return owner
+
+
+def gather_counters(values, device=None, group=None):
+    """The ONE collective of a sharded folder job: every rank contributes a flat list of floats (its counters), every
+    rank gets the list of all ranks' lists.  ``device``: where the exchange tensor lives (the rank's GPU for RCCL)."""
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [t.tolist()]
+    allt = [torch.zeros_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(allt, t, group=group)
+    return [x.tolist() for x in allt]
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def exec_ranks(nproc, target, env_extra=None):
+    """Become the launcher of an N-rank single-node job: replace this process by ``python -m torch.distributed.run
+    --nnodes=1 --nproc-per-node nproc --master-addr 127.0.0.1 --master-port <free> <target...>`` (``target``: a script
+    path or ``["-m", module]`` followed by its arguments).  One process per GPU; HSA_ENABLE_IPC_MODE_LEGACY=0 selects the
+    dmabuf IPC this host driver needs for RCCL across processes.  Does not return."""
+    import os
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // (2 * nproc))))
+    env.update(env_extra or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port())] + list(target)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def scatter_utterances(wavs_on_root, n_samples, device, group=None, root=0):
     """Rank ``root`` holds a float32 tensor (n_utt, n_samples); every rank receives its block
     (shard_range) as a device tensor.  Point-to-point sends: xGMI is a full mesh, a ring buys

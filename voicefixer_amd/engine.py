@@ -598,8 +598,11 @@ class Pipeline:
         # concurrently (restore_batch / restore_folder: set_streams(> 1)) two of them could hold the same entry at once
         # -- stream 1's copy into static_in is unordered against stream 0's replay -- so the replay path is bypassed
         # there; sequential users on DIFFERENT streams are ordered through the entry's event.
+        # While ``gru_single`` is set (run_checked's re-run after a missed two-CU hand-off) the replay path is bypassed
+        # too: a captured graph has the two-CU kernel baked in (replaying it would not be the miss-proof re-run), and a
+        # shape first seen during a re-run would be captured with the slower one-workgroup kernel for good.
         if graphs is not None and vocoder_func is None and ops.PROFILE is None and wav.shape[0] <= self._graph_cap[1] \
-                and N >= 1025 and getattr(self, "_n_streams", 1) == 1:
+                and N >= 1025 and getattr(self, "_n_streams", 1) == 1 and not self.restorer.gru_single:
             key = (wav.shape[0], N)
             ent = graphs.pop(key, None)
             if ent is None:

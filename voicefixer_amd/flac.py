@@ -23,6 +23,7 @@ Two implementations of the frame level, bit-exact against each other in both dir
     STREAMINFO, the MD5 check and argument checking are shared Python code either way.
 """
 import ctypes
+import threading
 import hashlib
 import os
 import struct
@@ -58,29 +59,39 @@ def build_native(verbose=False):
     return os.path.join(here, "libvfx_audio.so")
 
 
+_NATIVE_LOCK = threading.Lock()
+
+
 def native():
-    """ctypes handle of libvfx_audio.so, or None (not built, or VFX_FLAC_NATIVE=0)."""
+    """ctypes handle of libvfx_audio.so, or None (not built, or VFX_FLAC_NATIVE=0).  Thread-safe: restore_folder's
+    decode workers may be the first callers, all at once -- the handle is built under a lock and published only when
+    its prototypes are complete, so no thread can see a half-initialised state and fall back to the Python codec."""
     global _NATIVE
     if _NATIVE is None:
-        _NATIVE = False
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfx_audio.so")
-        if os.environ.get("VFX_FLAC_NATIVE", "1") != "0" and os.path.exists(path):
-            h = ctypes.CDLL(path)
-            u8p, i32p = ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int)
-            ull, ullp = ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong)
-            h.vfx_audio_version.restype = ctypes.c_int
-            h.vfx_flac_decode_frames.restype = ctypes.c_int
-            h.vfx_flac_decode_frames.argtypes = [ctypes.c_char_p, ull, ull, ctypes.c_int, ctypes.c_int, i32p, ull, ullp,
-                                                 ctypes.c_int, ullp]
-            h.vfx_flac_encode_frames.restype = ctypes.c_longlong
-            h.vfx_flac_encode_frames.argtypes = [i32p, ull, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ull,
-                                                 ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
-            f32p = ctypes.POINTER(ctypes.c_float)
-            h.vfx_resample_poly_f32.restype = ctypes.c_int      # (audio_io.resample_hq; same library)
-            h.vfx_resample_poly_f32.argtypes = [f32p, ull, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, ull]
-            if h.vfx_audio_version() >= 100:
-                _NATIVE = h
+        with _NATIVE_LOCK:
+            if _NATIVE is None:
+                _NATIVE = _load_native() or False
     return _NATIVE or None
+
+
+def _load_native():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfx_audio.so")
+    if os.environ.get("VFX_FLAC_NATIVE", "1") == "0" or not os.path.exists(path):
+        return None
+    h = ctypes.CDLL(path)
+    u8p, i32p = ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int)
+    ull, ullp = ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_ulonglong)
+    h.vfx_audio_version.restype = ctypes.c_int
+    h.vfx_flac_decode_frames.restype = ctypes.c_int
+    h.vfx_flac_decode_frames.argtypes = [ctypes.c_char_p, ull, ull, ctypes.c_int, ctypes.c_int, i32p, ull, ullp,
+                                         ctypes.c_int, ullp]
+    h.vfx_flac_encode_frames.restype = ctypes.c_longlong
+    h.vfx_flac_encode_frames.argtypes = [i32p, ull, ctypes.c_int, ctypes.c_int, ctypes.c_int, u8p, ull,
+                                         ctypes.POINTER(ctypes.c_uint), ctypes.POINTER(ctypes.c_uint)]
+    f32p = ctypes.POINTER(ctypes.c_float)
+    h.vfx_resample_poly_f32.restype = ctypes.c_int      # (audio_io.resample_hq; same library)
+    h.vfx_resample_poly_f32.argtypes = [f32p, ull, f32p, ctypes.c_int, ctypes.c_int, ctypes.c_int, f32p, ull]
+    return h if h.vfx_audio_version() >= 100 else None
 
 
 def _decode_frames_native(h, data, pos, nch, bps0, total, verify):
@@ -318,12 +329,17 @@ def decode(data, verify=True, use_native=None):
         if hdr & 0x7F == 0:
             v = int.from_bytes(body[10:18], "big")
             info = {"sr": v >> 44, "ch": ((v >> 41) & 7) + 1, "bps": ((v >> 36) & 31) + 1, "total": v & ((1 << 36) - 1),
-                    "md5": body[18:34]}
+                    "md5": body[18:34], "max_block": int.from_bytes(body[2:4], "big") or 65535}
         if hdr & 0x80:
             break
     if info is None:
         raise FlacError("FLAC: no STREAMINFO block")
     nch, bps0 = info["ch"], info["bps"]
+    # STREAMINFO's 36-bit sample count is untrusted input: a frame is at least 9 bytes (header, one subframe byte,
+    # CRC-16) and holds at most max_block samples, so the file cannot contain more than this -- a crafted count must
+    # not size an allocation
+    if info["total"] > ((len(data) - pos) // 9 + 1) * info["max_block"]:
+        raise FlacError("FLAC: STREAMINFO announces %d samples, the %d bytes of frames cannot hold them" % (info["total"], len(data) - pos))
     h = native() if use_native is None else (native() if use_native else None)
     if h is not None and info["total"] > 0 and 4 <= bps0 <= 32:
         pcm = _decode_frames_native(h, bytes(data), pos, nch, bps0, info["total"], verify)
