@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--wd", action="store_true", help="offer the convw_kernel weight layout (vfx_act.w_direct)")
     ap.add_argument("--wg", action="store_true", help="fused layers (rb*): the second half as Winograd F(2,3); "
                     "TFLOP/s stay the DIRECT algorithm's 2*MACs / time")
+    ap.add_argument("--stack", action="store_true", help="1-D k = 3 shapes as the ResStack issues them: dilation 1 = the SECOND convolution of a "
+                    "layer (no pre-activation, no post-activation, residual updated in place), otherwise the first (lrelu before and after)")
     ap.add_argument("--wg4", action="store_true", help="offer the Winograd F(4,3) weights (vfx_act.w_wino4; k = 3 1-D shapes; fused C = 64 layers: their second half)")
     args = ap.parse_args()
     dev = "cuda"
@@ -91,7 +93,11 @@ def main():
             pad = 1 if kind == "c1r" else 0
             wd = packing.pack_direct(wp).to(dev) if args.wd else None
             wg4 = packing.pack_wino4(wp).to(dev) if (args.wg4 and k == 3) else None
-            fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd, wg4=wg4)
+            if args.stack and k == 3 and dil == 1 and kind == "c1":
+                a2 = ops.Act()
+                fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, a2, res=y, w3=w3, wd=wd, wg4=wg4)
+            else:
+                fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd, wg4=wg4)
             macs = B * L * cin * cout * k
         elif kind == "rb":
             x = ops.guarded(B, cin, L, 2187 + 264, dev)

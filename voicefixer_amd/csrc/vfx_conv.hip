@@ -47,9 +47,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #if VFX_ABL & 8
 // development: per-phase cycle totals (wave 0 of every workgroup), read back with vfx_debug_read
 __device__ unsigned long long g_dbg[10];
+__device__ unsigned long long g_dbgx[6];   // convwg4_kernel: finer prologue split (vfx_debug_read_x)
 extern "C" int vfx_debug_read(unsigned long long* out, int reset) {
     hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 10);
     if (reset) { unsigned long long z[10] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), z, sizeof(z)); }
+    return 0;
+}
+extern "C" int vfx_debug_read_x(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbgx), sizeof(unsigned long long) * 6);
+    if (reset) { unsigned long long z[6] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbgx), z, sizeof(z)); }
     return 0;
 }
 #define DBG_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
