@@ -42,6 +42,7 @@ SHAPES = {
     "unet6": ("c2", 384, 384, 32, 2, 0),
     "unet6q": ("c2", 96, 384, 32, 2, 0),
     "gru_proj": ("c1", 512, 1536, 1001, 1, 1),
+    "post_k7": ("co1", 64, 1, 443646, 7, 1),   # ReflectionPad1d(3) + Conv1d(64, 1, 7) + Tanh: HBM-bound (reports GB/s in the TFLOP/s column / 1000)
     # what-if shapes (not in the model): long K at a fixed output tile count, to separate per-tile overhead from the loop
     "k3072": ("c1", 1024, 256, 49294, 3, 1),
     "k6144": ("c1", 2048, 256, 49294, 3, 1),
@@ -99,6 +100,15 @@ def main():
             else:
                 fn = lambda: ops.conv1d(x, w, bias, y, L, k, dil, pad, act, w3=w3, wd=wd, wg4=wg4)
             macs = B * L * cin * cout * k
+        elif kind == "co1":
+            Lp = (L + 3) // 4 * 4
+            x = ops.guarded(B, cin, L, 264, dev)
+            x.normal_()
+            y = torch.empty((B, 1, Lp), device=dev)
+            wc = torch.randn((cin, k), generator=g).to(dev).contiguous()
+            bias = torch.zeros(1, device=dev)
+            fn = lambda: ops.conv1d_cout1(x, wc, bias, y, L, k, _lib.PAD_REFLECT, _lib.POST_TANH)
+            macs = B * L * (cin + 1) * 4 / 2 * 1e3     # bytes / 2 * 1000: the printed "TFLOP/s" figure is GB/s / 1000 ... x 1000 = GB/s
         elif kind == "rb":
             x = ops.guarded(B, cin, L, 2187 + 264, dev)
             x.normal_()

@@ -56,6 +56,76 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
     y[(long long)b * y_bs + l] = acc;
 }
 
+// The k = 7 instance of the vocoder's last convolution (ReflectionPad1d(3) + Conv1d(64, 1, 7) + Tanh, generator.py:100,145) reads
+// 3.7 GB at batch 32 and is HBM-bound by its bytes -- but with one thread per output and seven dword loads per channel it
+// issued 448 load instructions per thread and ran at 3.3 TB/s, bound by the texture addresser's instruction rate, not by HBM
+// (round 3: 1.265 ms).  Here a thread owns FOUR consecutive outputs l .. l+3 (l a multiple of 4): per channel three aligned
+// 16-byte loads deliver x[l-4 .. l+7], of which the 28 products use x[l-3 .. l+6] -- 0.75 load instructions per output and
+// channel instead of 7.  Threads whose window leaves the row (the first and the last of a row: reflect / zero padding, ragged row
+// ends) take the per-element index path of conv_cout1_kernel for their four outputs.
+__global__ __launch_bounds__(256) void conv_cout1x4_k7_kernel(const float* __restrict__ x, long long x_bs, long long x_cs,
+                                                              const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ y, long long y_bs, int Cin, int L0,
+                                                              int reflect, int post_act, const int* __restrict__ rows) {
+    const int l = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int b = blockIdx.y;
+    const int L = rows ? rows[b] : L0;
+    if (l >= L) return;
+    const float* xb = x + (long long)b * x_bs;
+    const float b0 = bias ? bias[0] : 0.f;
+    float acc[4] = {b0, b0, b0, b0};
+    if (l >= 4 && l + 8 <= L) {
+        const float* p = xb + l - 4;
+#pragma unroll 4
+        for (int c = 0; c < Cin; ++c) {
+            const float4 v0 = *reinterpret_cast<const float4*>(p);
+            const float4 v1 = *reinterpret_cast<const float4*>(p + 4);
+            const float4 v2 = *reinterpret_cast<const float4*>(p + 8);
+            p += x_cs;
+            const float e[12] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w};   // e[i] = x[l - 4 + i]
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const float wt = w[c * 7 + t];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) acc[o] = fmaf(wt, e[o + t + 1], acc[o]);   // x[l + o + t - 3]
+            }
+        }
+    } else {
+        for (int o = 0; o < 4; ++o) {
+            if (l + o >= L) break;
+            int idx[7];
+            bool ok[7];
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                int g = l + o + t - 3;
+                ok[t] = true;
+                if (reflect) {
+                    if (g < 0) g = -g;
+                    if (g >= L) g = 2 * (L - 1) - g;
+                } else if (g < 0 || g >= L) {
+                    ok[t] = false;
+                    g = 0;
+                }
+                idx[t] = g;
+            }
+            float s = b0;
+            for (int c = 0; c < Cin; ++c) {
+                const float* row = xb + (long long)c * x_cs;
+#pragma unroll
+                for (int t = 0; t < 7; ++t) s = fmaf(w[c * 7 + t], ok[t] ? row[idx[t]] : 0.f, s);
+            }
+            acc[o] = s;
+        }
+    }
+    float* yo = y + (long long)b * y_bs + l;
+    if (l + 4 <= L) {
+        *reinterpret_cast<float4*>(yo) = make_float4(vfx_post(acc[0], post_act, 0.f), vfx_post(acc[1], post_act, 0.f),
+                                                     vfx_post(acc[2], post_act, 0.f), vfx_post(acc[3], post_act, 0.f));
+    } else {
+        for (int o = 0; o < 4 && l + o < L; ++o) yo[o] = vfx_post(acc[o], post_act, 0.f);
+    }
+}
+
 extern "C" int vfx_conv1d_cout1_f32(const vfx_tensor* x, const float* w, const float* bias, const vfx_tensor* y,
                                     int B, int Cin, int L, int k, int pad_mode, int post_act, int out_mask_log2,
                                     vfx_stream_t stream) {
@@ -65,7 +135,14 @@ extern "C" int vfx_conv1d_cout1_f32(const vfx_tensor* x, const float* w, const f
     dim3 grid((L + 255) / 256, B);
     const int mask = out_mask_log2 > 0 ? (1 << out_mask_log2) - 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (k == 7)
+    static const bool x4_off = getenv("VFX_COUT1_X4") && atoi(getenv("VFX_COUT1_X4")) == 0;   // development
+    const bool vec_ok = !x4_off && mask == 0 && ((x->cstride | x->bstride | y->bstride) & 3) == 0 &&
+                        (((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0;
+    if (k == 7 && vec_ok)
+        hipLaunchKernelGGL(conv_cout1x4_k7_kernel, dim3((L + 1023) / 1024, B), dim3(256), 0, s, (const float*)x->ptr, x->bstride,
+                           x->cstride, w, bias, (float*)y->ptr, y->bstride, Cin, L, pad_mode == VFX_PAD_REFLECT, post_act,
+                           (const int*)x->rows);
+    else if (k == 7)
         hipLaunchKernelGGL(conv_cout1_kernel<7>, grid, dim3(256), 0, s, (const float*)x->ptr, x->bstride, x->cstride,
                            w, bias, (float*)y->ptr, y->bstride, Cin, L, pad_mode == VFX_PAD_REFLECT, post_act, mask,
                            (const int*)x->rows);
