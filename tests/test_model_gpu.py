@@ -276,3 +276,78 @@ def test_four_full_length_rows_of_a_batch32_run_against_the_oracle(pipe, seeded_
             ref = oracle.restore_inmem(batch[b].numpy(), vsd, rsd)
             worst = max(worst, _rms(out[b].cpu().numpy(), ref[0]))
     assert worst < RMS_TOL, worst
+
+
+def test_batch32_intermediates_against_the_oracle(pipe, seeded_states):
+    """at the batch-32 launch geometry parity was only checked on the waveform, so a compensating error in
+    one stage would not be localised.  Here every intermediate of the path -- mel, denoiser mask, UNet output, log-mel,
+    vocoder conditioning, condnet output, the four up-stage outputs, waveform -- is compared with the oracle's for three rows
+    of a batch of 32 (first, middle, last: every row is its own utterance)."""
+    from oracle import oracle
+    vsd, rsd = seeded_states
+    n = 30000
+    g = torch.Generator().manual_seed(199)
+    t = torch.arange(n, dtype=torch.float32) / 44100.0
+    f0 = 100.0 + 15.0 * torch.arange(32, dtype=torch.float32)[:, None]
+    batch = 0.08 * torch.randn(32, n, generator=g) + 0.25 * torch.sin(2 * np.pi * f0 * t[None])
+    rep = pipe.stage_report(batch.cuda(), n)
+    torch.cuda.synchronize()
+    pipe.check()
+    got = {k: v.cpu() for k, v in rep.items()}
+
+    def rel(a, b):
+        return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+    worst = {}
+    with torch.no_grad():
+        for b in (0, 17, 31):
+            mel = oracle.wav_to_mel(batch[b:b + 1])                     # (1, 1, T, 128)
+            r = oracle.restorer_forward(mel, rsd, return_all=True)
+            den = oracle.from_log(r["mel"])
+            cond = oracle.mel_to_cond(den)
+            st = {}
+            wav = oracle.vocoder_generator(cond, vsd, stages=st)
+            ref = oracle.restore_inmem(batch[b].numpy(), vsd, rsd)
+            want = {"mel": mel[0, 0], "mask": r["mask"][0, 0], "unet_out": r["unet_out"][0, 0], "logmel": r["mel"][0, 0],
+                    "denoised": den[0, 0], "cond": cond[0], "condnet": st["condnet"][0], "up1": st["up1"][0], "up2": st["up2"][0],
+                    "up3": st["up3"][0], "up4": st["up4"][0], "wav": torch.from_numpy(ref[0])}
+            for k, w in want.items():
+                assert got[k][b].shape == w.shape, (k, got[k][b].shape, w.shape)
+                worst[k] = max(worst.get(k, 0.0), rel(got[k][b], w))
+    # relative to each stage's own peak; the UNet output (values of a few units after ~100 convolutions) gets the golden test's bound
+    # (measured: mel / mask 2e-7, UNet output 3e-6, conditioning 1e-6, up-stages 3e-6 .. 1.5e-5, waveform 1.6e-5)
+    bounds = {"mel": 1e-5, "mask": 1e-5, "unet_out": 1e-4, "logmel": 1e-4, "denoised": 1e-4, "cond": 1e-4, "condnet": 1e-4,
+              "up1": 1e-4, "up2": 1e-4, "up3": 1e-4, "up4": 1e-4, "wav": 1e-4}
+    print("worst relative difference per stage:", {k: "%.2e" % v for k, v in worst.items()})
+    for k, v in worst.items():
+        assert v < bounds[k], (k, v, worst)
+
+
+def test_selfcheck_default_direct_bf16x3_agree_stage_by_stage(pipe):
+    """voicefixer_amd/selfcheck.py (python -m voicefixer_amd --selfcheck): the three arithmetics on one input, every stage within
+    1e-4 of the direct sums' peak -- and the switch really switches (direct issues no Winograd launch, default does)."""
+    from voicefixer_amd import selfcheck, engine, _lib, ops
+    n = 44100
+    g = torch.Generator().manual_seed(7)
+    t = torch.arange(n, dtype=torch.float32) / 44100.0
+    wav = (0.05 * torch.randn(4, n, generator=g) + 0.2 * torch.sin(2 * np.pi * 200.0 * t)[None]).cuda()
+    res = selfcheck.run_variants(pipe, wav, n)
+    bad, table = selfcheck.report(res, 1e-4)
+    assert not bad, bad
+    assert 0 < table["default"]["wav_rms"] < 2e-5 and 0 < table["bf16x3"]["wav_rms"] < 2e-5    # different arithmetic, same answer
+    assert engine._ARITH["winograd"] and pipe.math == "f32"
+    try:
+        ops.PROFILE = []
+        engine.set_winograd(False)
+        pipe.restore(wav, n)
+        torch.cuda.synchronize()
+        direct_codes = {p[0] % 100 for p in ops.PROFILE if p[0] != -1}
+        ops.PROFILE = []
+        engine.set_winograd(True)
+        pipe.restore(wav, n)
+        torch.cuda.synchronize()
+        wino_codes = {p[0] % 100 for p in ops.PROFILE if p[0] != -1}
+    finally:
+        ops.PROFILE = None
+        engine.set_winograd(True)
+    assert not ({80, 88, 91, 92, 94, 71, 72, 74} & direct_codes) and 80 in wino_codes and (wino_codes & {88, 91, 92, 94})

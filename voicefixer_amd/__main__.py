@@ -15,6 +15,9 @@ Differences, all deliberate:
     re-executes itself under ``torch.distributed.run`` on 127.0.0.1 (N clamped, loudly, to the visible devices), every
     rank lists the folder, takes the files ``dist.deal_files`` deals it and writes their outputs; the only collective is
     one all-gather of per-rank counters at the end (RCCL);
+  * ``--selfcheck [IN.wav]`` (extension): runs the input through the path with the default (Winograd), the direct and the
+    opt-in bf16x3 arithmetic and compares them stage by stage (voicefixer_amd/selfcheck.py) -- the one-command check for
+    users with real checkpoints;
   * output formats are WAV and FLAC (``audio_io.FORMATS``) instead of whatever libsndfile offers.
 """
 import argparse
@@ -124,6 +127,10 @@ def report_ranks(per_rank, silent):
 
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else list(argv)
+    if "--selfcheck" in argv:      # (extension) default vs direct vs bf16x3 arithmetic on the loaded checkpoint, stage by stage
+        from . import selfcheck
+        i = argv.index("--selfcheck")
+        return selfcheck.main(argv[:i] + argv[i + 1:])
     args = build_parser().parse_args(argv)
     if args.weight_prepare:
         from . import api

@@ -97,6 +97,21 @@ WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
 WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
 
 
+# Run-time arithmetic switch (voicefixer_amd/selfcheck.py): False = no launch is offered its Winograd-transformed weights, so
+# every k = 3 / 3x3 convolution runs as the direct sum (the fused C = 64 layer: both halves direct).  The weights stay packed.
+_ARITH = {"winograd": True}
+
+
+def set_winograd(on):
+    """True (default): k = 3 / 3x3 convolutions as Winograd F(4,3) where the kernels take them; False: direct sums everywhere.
+    Same operands, same fp32 accumulation -- only the order of the sums (and the products formed) differs."""
+    _ARITH["winograd"] = bool(on)
+
+
+def _wg(w):
+    return w if _ARITH["winograd"] else None
+
+
 class VocoderEngine:
     """TFGAN-style 44.1 kHz generator: cond (B,128,T') -> wav (B,1,441*T')."""
 
@@ -176,7 +191,7 @@ class VocoderEngine:
         for i, (w, wd, bias, wg) in enumerate(self.condnet):
             y = a if i % 2 == 0 else b
             ops.conv1d(x, w, bias, y, Tc, 3, 1, PAD_ZERO, self.act_elu, w3=self._x3(w), wd=wd,
-                       wg4=wg if self.math == "f32" else None)
+                       wg4=_wg(wg) if self.math == "f32" else None)
             x = y
         if stages is not None:
             stages["condnet"] = x[:, :, :Tc]
@@ -193,7 +208,7 @@ class VocoderEngine:
             mult *= s
             # (the fused kernel addresses one batch item with 32-bit byte offsets: rows of more than ~3 minutes at the last
             # stage fall back to the two-launch form, whose first-generation kernel has no such limit)
-            wino = layers[0][7] is not None and self.math == "f32"
+            wino = layers[0][7] is not None and self.math == "f32" and _ARITH["winograd"]
             fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and not wino and
                      c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
             xs = _rows(B, c, Lo, G_DIL, dev, rows(mult))
@@ -210,7 +225,7 @@ class VocoderEngine:
                     if last:
                         post, pslope = (POST_LRELU if j == nst - 1 else POST_LRELU_SNAKE), 0.2
                     src, dst = (xs, ys) if i % 2 == 0 else (ys, xs)
-                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=w2g, w2g4=w2g4)
+                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=_wg(w2g), w2g4=_wg(w2g4))
                     continue
                 if not wino:
                     w1g4 = w2g4 = None
@@ -225,15 +240,17 @@ class VocoderEngine:
         ops.conv1d_cout1(h, self.post[0], self.post[1], wav, L, 7, PAD_REFLECT, POST_TANH)
         return wav, L
 
-    def forward(self, mel, T, ragged=None):
+    def forward(self, mel, T, ragged=None, stages=None):
         """mel: device (B,T,128) linear, non-normalised (Vocoder.forward semantics); ``ragged``: row b holds
-        ragged.T[b] <= T frames."""
+        ragged.T[b] <= T frames.  ``stages`` (optional dict) receives "cond", "condnet", "up1" .. "up4"."""
         B = mel.shape[0]
         Tc = T + T % 2 + 4
         if ragged is None:
             cond = _rows(B, weights.N_MELS, Tc, G_TILE, mel.device)
             ops.mel_to_cond(mel, cond, T)
-            return self.forward_cond(cond, Tc)
+            if stages is not None:
+                stages["cond"] = cond[:, :, :Tc].clone()
+            return self.forward_cond(cond, Tc, stages=stages)
         cond = _rows(B, weights.N_MELS, Tc, G_TILE, mel.device, ragged.voc[1])
         ops.mel_to_cond(mel, cond, T, ragged.T)
         return self.forward_cond(cond, Tc, ragged=ragged)
@@ -293,8 +310,8 @@ class _ConvBlock:
             res = out
         else:
             res = x
-        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg4=self.w1g4)
-        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg4=self.w2g4)
+        ops.conv2d(x, self.w1, self.b1, y1, H, lp, 3, self.act1, cin=self.cin, w3=self.x3[0], wd=self.w1d, wg4=_wg(self.w1g4))
+        ops.conv2d(y1, self.w2, None, out, H, lp, 3, None, res=res, w3=self.x3[1], wd=self.w2d, wg4=_wg(self.w2g4))
 
 
 class RestorerEngine:
@@ -552,6 +569,22 @@ class Pipeline:
                 return out
             finally:
                 self.restorer.gru_single = False
+
+    def stage_report(self, wav, N):
+        """The path's intermediates for one batch (selfcheck / parity tests): dict of device tensors -- "mel" (B,T,128),
+        "mask" (B,T,128), "unet_out" (B,T,128), "logmel", "denoised", "cond" (B,128,T'), "condnet" (B,512,T'),
+        "up1" .. "up4" (the four ConvTranspose1d outputs), "wav" (B,N): what ``restore`` returns."""
+        mel, T = self.wav_to_mel(wav, N)
+        dbg, st = {}, {}
+        logmel, den = self.restorer.forward(mel, T, debug=dbg)
+        y, Ly = self.vocoder.forward(den, T, stages=st)
+        out = torch.empty((wav.shape[0], min(N, Ly)), device=wav.device)
+        ws = torch.empty((wav.shape[0],), dtype=torch.int32, device=wav.device)
+        ops.post(y[:, 0], Ly, out, out.shape[1], ws)
+        rep = {"mel": mel, "mask": dbg["mask"].transpose(1, 2).contiguous(), "unet_out": dbg["unet_out"].contiguous(),
+               "logmel": logmel, "denoised": den, "wav": out}
+        rep.update({k: v.clone() for k, v in st.items()})
+        return rep
 
     def wav_to_mel(self, wav, N):
         B = wav.shape[0]
