@@ -529,7 +529,7 @@ def main():
 
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
-    # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 16: conv_x3_kernel,
+    # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 96: resblk4_kernel (fused layer, both halves F(4,3)), 16: conv_x3_kernel,
     # 80: convwg4_kernel (Winograd F(4,3), 1-D), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74 | 91/92/94: fused layer with a Winograd F(2,3) | F(4,3) second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
@@ -552,6 +552,8 @@ def main():
         if code in (91, 92, 94):
             return ("wfusedw4", bm, bl), "convw_kernel<%d,%d,*,*,3,*,3> (fused ResStack layer, Winograd F(4,3) second half)" % (bm, bl), \
                    r"convw_kernel<%d, %d, \d+, \d+, 3, \d+, 3>" % (bm, bl)
+        if code == 96:
+            return ("wfusedw44", bm, bl), "resblk4_kernel (fused ResStack layer, both halves Winograd F(4,3))", r"resblk4_kernel"
         if code == 88:
             wgm = bm // 32
             return ("wino4", bm, bl, 3, "s"), "convwg4s_kernel<%d,%d,*> (3x3 as Winograd F(4,3) along the map rows, kernel columns share one staged tile)" % (
@@ -575,6 +577,8 @@ def main():
             return 5.0 / 6.0   # the dilated half direct (3 products per output), the dilation-1 half Winograd F(2,3) (2)
         if key[0] == "wfusedw4":
             return 0.75        # the dilated half direct (3 products per output), the dilation-1 half Winograd F(4,3) (1.5)
+        if key[0] == "wfusedw44":
+            return 0.5         # both halves Winograd F(4,3)
         return 1.0
 
     by_fam = {}
@@ -678,7 +682,7 @@ def main():
                                % (args.batch, args.seconds),
                    "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "frames": 1 + n // 441,
                    "arithmetic": ("fp32 operands, fp32 MFMA accumulation everywhere; k=3 / 3x3 convolutions evaluated as Winograd "
-                                  "F(4,3) (the fused C=64 layer: its dilation-1 half, on the LDS tile; its dilated half is the direct sum): half "
+                                  "F(4,3) (the fused C=64 layer: both halves for dilations <= 27, the dilation-1 half for the wider ones): half "
                                   "of the direct sum's products, rounding ~3x the direct sum's (DESIGN.md 3.0b; VFX_WINO=0 runs the direct sums)") if args.math == "f32"
                                  else "opt-in split-bf16 products (three bf16 MFMAs per fp32 product), fp32 accumulation",
                    "parallelism": "utterance sharding x%d (no data-path collective)" % world},

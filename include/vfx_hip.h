@@ -126,6 +126,7 @@ uint64_t vfx_launch_count(void);
  *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels)
  *   code 71 / 72 / 74 convw_kernel<BM,BL,*,*,3,*,2>              (vfx_resblock2_f32: second half as Winograd F(2,3))
  *   code 91 / 92 / 94 convw_kernel<BM,BL,*,*,3,*,3>              (vfx_resblock3_f32: second half as Winograd F(4,3))
+ *   code 96           resblk4_kernel                             (vfx_resblock4_f32: both halves as Winograd F(4,3))
  *   code 80           convwg4_kernel<..>                          (Winograd F(4,3), 1-D), BL = output positions
  *   code 88           convwg4s_kernel<..>                         (Winograd F(4,3), 3x3 on a pitch map, kernel columns share one tile) */
 int vfx_last_conv_tile(void);
@@ -166,6 +167,16 @@ int vfx_resblock2_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_
 int vfx_resblock3_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
                       const float* w2_direct, const float* bias2, const float* w2_wino, const float* w2_wino4,
                       int B, int C, int L, int dilation, float slope, int post_act, float post_slope,
+                      vfx_stream_t stream);
+
+/* The same, with the FIRST (dilated) convolution's weights also offered as their Winograd F(4,3) transform (w1_wino4, may be NULL).
+ * C = 64 with both transforms, 16-byte aligned rows and a dilation whose blocks of 4 d positions fill a 256-column tile (d <= 32
+ * with >= 48 of 64 quad columns used: the stage's d = 1, 3, 9, 27): BOTH halves of the layer form 6 products per four outputs
+ * (resblk4_kernel: the dilated half along the dilated axis, its output transform into the LDS tile; x needs no guard band there).
+ * Anything else is vfx_resblock3_f32.  Results differ from vfx_resblock_f32 by fp32 rounding only. */
+int vfx_resblock4_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
+                      const float* w2_direct, const float* bias2, const float* w2_wino, const float* w2_wino4,
+                      const float* w1_wino4, int B, int C, int L, int dilation, float slope, int post_act, float post_slope,
                       vfx_stream_t stream);
 
 /* ConvTranspose1d(Cin, Cout, kernel 2s, stride s, padding s/2 + s%2, output_padding s%2):

@@ -409,6 +409,12 @@ RESBLOCK_CASES = [
     (1, 64, 252, 1, _lib.POST_LRELU),
     (2, 64, 506, 1, _lib.POST_NONE),           # two tiles and half a quad
     (2, 64, 20002, 9, _lib.POST_LRELU_SNAKE),
+    (1, 64, 247, 9, _lib.POST_NONE),           # both halves F(4,3), d = 9: 248 outputs (62 quads) per tile -- one tile minus one
+    (1, 64, 248, 3, _lib.POST_NONE),           # exactly one tile
+    (2, 64, 249, 9, _lib.POST_LRELU),          # one tile plus one output
+    (1, 64, 212, 27, _lib.POST_NONE),          # d = 27: two blocks of 108 columns, 53 output quads
+    (2, 64, 641, 27, _lib.POST_NONE),          # three tiles and one output
+    (1, 64, 30, 27, _lib.POST_NONE),           # a row shorter than one block of 4d positions
     (2, 128, 9000, 1, _lib.POST_NONE),
     (2, 128, 9001, 3, _lib.POST_LRELU),
     (2, 128, 9000, 27, _lib.POST_NONE),
@@ -475,6 +481,19 @@ def test_resblock_fused(case):
     _close(yd3[:, :, :L], ref, 2e-5)
     base = yd3._vfx_base
     assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()
+    # ... and with the FIRST (dilated) convolution as F(4,3) too (vfx_resblock4_f32, w1_wino4: resblk4_kernel) for the dilations whose
+    # blocks of 4d positions fit the 256-column tile (1, 3, 9, 27); wider dilations keep the form above
+    yd4 = ops.guarded(B, Cn, L, 2187 + 264, DEV)
+    yd4._vfx_base.fill_(float("nan"))
+    ops.resblock(xd, yd4, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2,
+                 w2g=packing.pack_wino(packing.pack_conv1d(w2)).to(DEV),
+                 w2g4=packing.pack_wino4(packing.pack_conv1d(w2)).to(DEV),
+                 w1g4=packing.pack_wino4(packing.pack_conv1d(w1)).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 in ((96,) if dil <= 27 else (91, 92, 94)), _lib.lib().vfx_last_conv_tile()
+    _close(yd4[:, :, :L], ref, 2e-5)
+    base = yd4._vfx_base
+    assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()
     # rows that are not 16-byte aligned fall back to the F(2,3) form
     if L > 8:
         yo = ops.guarded(B, Cn, L + 4, 2187 + 264, DEV)
@@ -487,6 +506,37 @@ def test_resblock_fused(case):
         assert _lib.lib().vfx_last_conv_tile() % 100 in (71, 72, 74)
         _close(yv, ref, 2e-5)
 
+
+
+@pytest.mark.parametrize("dil", [1, 3, 9, 27])
+def test_resblock_both_halves_winograd_ragged_rows(dil):
+    """resblk4_kernel on a ragged batch: every row equals the layer applied to that row alone (zero padding of BOTH convolutions at
+    the row's own end), nothing is written past a row's end."""
+    B, Cn, Lmax = 4, 64, 3000
+    lens = [3000, 2999, 1201, 500]
+    x = _rand((B, Cn, Lmax), 191)
+    w1 = _rand((Cn, Cn, 3), 192, (Cn * 3) ** -0.5)
+    b1 = _rand((Cn,), 193, 0.1)
+    w2 = _rand((Cn, Cn, 3), 194, (Cn * 3) ** -0.5)
+    b2 = _rand((Cn,), 195, 0.1)
+    rows = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    xd = ops.with_rows(_guarded_nan(x, 2187 + 264), rows)
+    for b, n in enumerate(lens):                 # what lies behind a row's end inside the buffer must not matter
+        xd[b, :, n:] = float("nan")
+    yd = ops.with_rows(ops.guarded(B, Cn, Lmax, 2187 + 264, DEV), rows)
+    yd._vfx_base.fill_(float("nan"))
+    pk = lambda w: packing.pack_conv1d(w)
+    ops.resblock(xd, yd, packing.pack_direct(pk(w1)).to(DEV), b1.to(DEV), packing.pack_direct(pk(w2)).to(DEV), b2.to(DEV), Lmax, dil,
+                 0.01, _lib.POST_NONE, 0.0, w2g=packing.pack_wino(pk(w2)).to(DEV), w2g4=packing.pack_wino4(pk(w2)).to(DEV),
+                 w1g4=packing.pack_wino4(pk(w1)).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 96
+    for b, n in enumerate(lens):
+        xb = x[b:b + 1, :, :n]
+        mid = F.conv1d(F.leaky_relu(xb, 0.01), w1, b1, dilation=dil, padding=dil)
+        ref = xb + F.conv1d(F.leaky_relu(mid, 0.01), w2, b2, padding=1)
+        _close(yd[b:b + 1, :, :n], ref, 2e-5)
+        assert torch.isnan(yd[b, :, n:Lmax]).all()
 
 
 def test_linear_transposed_output():

@@ -119,7 +119,8 @@ def main():
             w2p = packing.pack_conv1d(torch.randn((cout, cin, 3), generator=g) * (cin * 3) ** -0.5)
             w2g = packing.pack_wino(w2p).to(dev) if args.wg else None
             w2g4 = packing.pack_wino4(w2p).to(dev) if (args.wg4 and cin == 64) else None
-            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil, w2g=w2g, w2g4=w2g4)
+            w1g4 = packing.pack_wino4(w2p).to(dev) if (args.wg4 and cin == 64) else None     # (any weights do for timing)
+            fn = lambda: ops.resblock(x, y, w1d, bias, w2d, bias, L, dil, w2g=w2g, w2g4=w2g4, w1g4=w1g4)
             macs = 2 * B * L * cin * cout * 3
         elif kind == "t1":
             s = k

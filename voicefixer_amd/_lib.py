@@ -48,6 +48,7 @@ SIGNATURES = {
     "vfx_resblock_f32": (_I, [_T, _T, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
     "vfx_resblock2_f32": (_I, [_T, _T, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
     "vfx_resblock3_f32": (_I, [_T, _T, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
+    "vfx_resblock4_f32": (_I, [_T, _T, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
     "vfx_convtr1d_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_conv2d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_convtr2d_3x3s2_f32": (_I, [_T, _P, _T, _I, _I, _I, _I, _I, _A, _P]),

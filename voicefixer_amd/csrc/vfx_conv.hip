@@ -127,6 +127,7 @@ struct ConvArgs {
     const float* bias2;
     int yp;                 // row pitch of the intermediate tile (floats)
     float mid_slope;        // leaky-ReLU between the two convolutions
+    int rb_nq1;             // resblk4_kernel: quads of the first (dilated) half per tile = whole blocks of 4d columns x d
 };
 
 // Staging slots per thread.  The host picks KC (8 or 4) so that the activation tile never needs
@@ -1203,6 +1204,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 #include "vfx_convw.inc"
 #include "vfx_convwg.inc"
 #include "vfx_convwg2d.inc"
+#include "vfx_resblk4.inc"
 
 template <int BM, int BL, int WGM, int WGL, int NT, int MODE, int ROWS = 1>
 static int launch_x3_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {

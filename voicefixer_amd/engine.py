@@ -151,7 +151,8 @@ class VocoderEngine:
                               _wpair(wb, device) + (_dev(sd[b + ".bias"], device),) +
                               (_dev(packing.pack_wino(wb), device) if cst <= FUSE_MAX_C and not wino else None,) +
                               ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if wino
-                               else (None, _dev(packing.pack_wino4(wb), device) if cst == 64 else None)))
+                               else ((_dev(packing.pack_wino4(wa), device), _dev(packing.pack_wino4(wb), device)) if cst == 64
+                                     else (None, None))))
             self.stages.append((s, upw, layers))
         self.post = (_dev(packing.pack_cout1(wn("generator.16")), device), _dev(sd["generator.16.bias"], device))
         self.act_elu = ops.Act(post=POST_ELU)
@@ -208,7 +209,7 @@ class VocoderEngine:
             mult *= s
             # (the fused kernel addresses one batch item with 32-bit byte offsets: rows of more than ~3 minutes at the last
             # stage fall back to the two-launch form, whose first-generation kernel has no such limit)
-            wino = layers[0][7] is not None and self.math == "f32" and _ARITH["winograd"]
+            wino = layers[0][7] is not None and c >= WINO_MIN_C and self.math == "f32" and _ARITH["winograd"]
             fused = (_FUSE and self.math == "f32" and c <= FUSE_MAX_C and not wino and
                      c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
             xs = _rows(B, c, Lo, G_DIL, dev, rows(mult))
@@ -225,7 +226,8 @@ class VocoderEngine:
                     if last:
                         post, pslope = (POST_LRELU if j == nst - 1 else POST_LRELU_SNAKE), 0.2
                     src, dst = (xs, ys) if i % 2 == 0 else (ys, xs)
-                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=_wg(w2g), w2g4=_wg(w2g4))
+                    ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=_wg(w2g), w2g4=_wg(w2g4),
+                                 w1g4=_wg(w1g4))
                     continue
                 if not wino:
                     w1g4 = w2g4 = None
