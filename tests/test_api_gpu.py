@@ -818,3 +818,43 @@ def test_restore_folder_two_ranks_in_one_process_equal_the_unsharded_folder(vf, 
         _, x1 = wavfile.read(str(tmp_path / "whole" / f))
         _, x2 = wavfile.read(str(tmp_path / "sharded" / f))
         assert x1.shape == x2.shape and np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1
+
+
+def test_cli_folder_under_the_launcher_on_rccl(vf, seeded_states, tmp_path, monkeypatch):
+    """``python -m voicefixer_amd -ifdr .. --gpus N``: (a) started plain with --gpus 4 on this one-GPU box it clamps (loudly) to the
+    visible devices and runs; (b) started as torch.distributed.run starts it on every rank -- RANK / WORLD_SIZE in the
+    environment, backend nccl = RCCL -- it initialises the group, restores the files dist.deal_files deals the rank, exchanges the
+    per-rank counters with ONE all-gather on the device and prints the job summary.  World size 1 is all one GPU allows; world size
+    2 runs on gloo in tests/test_dist_cpu.py."""
+    import subprocess
+    import sys
+    from scipy.io import wavfile
+    _seeded_home(tmp_path, seeded_states, monkeypatch)
+    rng = np.random.default_rng(83)
+    ind = tmp_path / "in"
+    ind.mkdir()
+    for k in range(5):
+        n = int(rng.integers(15000, 40000))
+        audio_io.save_wave((0.2 * rng.standard_normal(n)).astype(np.float32)[None], str(ind / ("u%d.wav" % k)))
+    vf.restore_folder(str(ind), str(tmp_path / "want"), batch_size=2)
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (HOME: the seeded checkpoints)
+    root = env["PYTHONPATH"]
+    # (a) plain start, more GPUs asked for than the box has
+    r = subprocess.run([sys.executable, "-m", "voicefixer_amd", "-ifdr", str(ind), "-ofdr", str(tmp_path / "plain"), "--gpus", "4",
+                        "--batch-size", "2"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    if torch.cuda.device_count() < 4:
+        assert "--gpus 4 requested but only" in r.stderr
+    # (b) as a rank of the launcher, RCCL
+    port = 29000 + os.getpid() % 2000
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), "-m", "voicefixer_amd", "-ifdr", str(ind), "-ofdr", str(tmp_path / "ranked"),
+                        "--gpus", "1", "--batch-size", "2"], env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"), cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0: 5 files" in r.stdout and "whole job: 5 files" in r.stdout and "on 1 GPU(s)" in r.stdout
+    for out in ("plain", "ranked"):
+        assert sorted(os.listdir(tmp_path / out)) == sorted(os.listdir(tmp_path / "want"))
+        for f in os.listdir(tmp_path / "want"):
+            x1, x2 = wavfile.read(str(tmp_path / out / f))[1], wavfile.read(str(tmp_path / "want" / f))[1]
+            assert x1.shape == x2.shape and np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1

@@ -154,7 +154,8 @@ def main(argv=None):
     if args.gpus > 1 and process_folder and "WORLD_SIZE" not in os.environ:
         folder_ranks(args, argv)      # does not return when it re-executes under torch.distributed.run
     rank = 0
-    if world > 1:
+    launched = "WORLD_SIZE" in os.environ     # started by torch.distributed.run (our own --gpus N launch, or the user's)
+    if launched:
         import torch.distributed as tdist
         rank = int(os.environ.get("RANK", "0"))
         if torch.cuda.is_available():
@@ -186,7 +187,7 @@ def main(argv=None):
             st = {}
             voicefixer.restore_folder(args.infolder, args.outfolder, mode=m, batch_size=args.batch_size,
                                       name_suffix="-mode%d" % m if append else "", stats=st)
-            if world > 1:
+            if launched:
                 dev = torch.device("cuda", torch.cuda.current_device()) if args.dist_backend == "nccl" else None
                 per_rank = vdist.gather_counters([st["files"], st["audio_s"], st["wall_s"], st["decode_worker_s"],
                                                   st["encode_worker_s"], st["device_waited_for_decode_s"]], dev)
@@ -194,7 +195,7 @@ def main(argv=None):
                     report_ranks(per_rank, args.silent)
             if not args.silent:
                 print("Restoration of %d files (mode %d) took %s s" % (n_files, m, round(time.time() - start, 1)))
-    if world > 1:
+    if launched:
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
