@@ -557,11 +557,11 @@ def main():
         if code == 88:
             wgm = bm // 32
             return ("wino4", bm, bl, 3, "s"), "convwg4s_kernel<%d,%d,*> (3x3 as Winograd F(4,3) along the map rows, kernel columns share one staged tile)" % (
-                wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+>" % (wgm, 4 // wgm)
+                wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+[,>]" % (wgm, 4 // wgm)
         if code == 80:
             wgm = bm // 32
             return ("wino4", bm, bl), "convwg4_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; D1 = the dilation-1 instance)" % (
-                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, (true|false)>" % (wgm, 4 // wgm)
+                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, (true|false)[,>]" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
