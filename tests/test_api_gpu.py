@@ -754,7 +754,7 @@ def test_gru_retry_with_graphs_enabled_runs_eager(vf):
         pipe.restorer.gru_single = True
         try:
             n_graphs = len(pipe._graphs)
-            pipe.restore(torch.from_numpy(gg["wav"][None, :20000]).cuda(), 20000)
+            pipe.restore(torch.from_numpy(gg["wav"][None, :12000]).cuda(), 12000)
             assert len(pipe._graphs) == n_graphs
         finally:
             pipe.restorer.gru_single = False
@@ -858,3 +858,34 @@ def test_cli_folder_under_the_launcher_on_rccl(vf, seeded_states, tmp_path, monk
         for f in os.listdir(tmp_path / "want"):
             x1, x2 = wavfile.read(str(tmp_path / out / f))[1], wavfile.read(str(tmp_path / "want" / f))[1]
             assert x1.shape == x2.shape and np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1
+
+
+def test_graph_replays_survive_an_eager_pass_in_between(seeded_states):
+    """Round 4 regression: capture, two replays, ONE eager pass of the same shape on the same stream, replays again -- with the peak
+    workspace and the GRU mailboxes zeroed by hipMemsetAsync (= memset nodes in the captured graph) every replay after the eager
+    pass returned the waveform scaled by the peak rule's stale workspace.  The zeroing is a kernel now; the sequence must be
+    bit-exact, on a fresh pipeline (the allocator state matters) and for both GRU kernels in the eager pass."""
+    from voicefixer_amd import engine
+    gg = np.load(os.path.join(GOLDEN, "restore_noise_T36.npz"))
+    x = torch.from_numpy(gg["wav"])[None].cuda()
+    n = x.shape[1]
+    for single in (False, True):
+        pipe = engine.Pipeline(seeded_states[0], seeded_states[1], "cuda:0")
+        want = pipe.restore(x, n).clone()
+        pipe.enable_graphs(max_shapes=2, max_batch=1)
+        try:
+            a, b = pipe.restore(x, n).clone(), pipe.restore(x, n).clone()
+            assert len(pipe._graphs) == 1 and torch.equal(a, want) and torch.equal(b, want)
+            graphs, pipe._graphs = pipe._graphs, None          # an eager pass while the captured graph stays alive
+            pipe.restorer.gru_single = single
+            try:
+                e = pipe.restore(x, n).clone()
+            finally:
+                pipe.restorer.gru_single = False
+                pipe._graphs = graphs
+            assert float((e - want).abs().max()) < 2e-5
+            c, d = pipe.restore(x, n).clone(), pipe.restore(x, n).clone()
+            assert torch.equal(c, want) and torch.equal(d, want), (float((c - want).abs().max()), float((d - want).abs().max()))
+            pipe.check()
+        finally:
+            pipe.disable_graphs()

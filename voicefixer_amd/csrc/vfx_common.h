@@ -14,6 +14,9 @@ static inline int vfx_last_error() {
     return e == hipSuccess ? VFX_OK : (int)e;
 }
 
+// Zero ``bytes`` (a multiple of 4) of device memory on a stream with a KERNEL (vfx_misc.hip), not hipMemsetAsync: see there.
+int vfx_zero_u32(void* p, size_t bytes, hipStream_t s);
+
 static inline bool vfx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 __device__ __forceinline__ float vfx_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }

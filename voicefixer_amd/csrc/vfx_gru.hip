@@ -218,7 +218,7 @@ extern "C" void vfx_gru_layout(int* kreg, int* klds, int* kstr) {
 // units (units 128r .. 128r+127 == its own k range, so h never has to travel) and hands the other
 // 384 to its partner through 8-byte {tag = step+1, value} granules written with ONE agent-scope
 // relaxed store each (MI355X guide, hand-off recipe R2: the data is the flag, no fence).  The
-// receiver polls with relaxed agent-scope loads.  Mailboxes are zeroed by a memset node before every
+// receiver polls with relaxed agent-scope loads.  Mailboxes are zeroed by a kernel (vfx_zero_u32: not a memset node, see vfx_misc.hip) before every
 // launch; spins are bounded and raise a device flag instead of hanging.
 // Residency: partners have adjacent block ids and the host never launches more workgroups than CUs.
 // (Round 3 tried the partners w and w + 8 -- workgroup ids are dealt round-robin to the 8 XCDs, so both land on one XCD
@@ -376,8 +376,8 @@ extern "C" int vfx_gru_bidir2_f32(const float* gi, const float* whh_t, const flo
     const size_t need = (size_t)B * 2 * 2 * 2 * 384 * sizeof(u64);
     if (mailbox_bytes < need) return VFX_ERANGE;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(mailbox, 0, need, s);
-    if (e != hipSuccess) return (int)e;
+    int e = vfx_zero_u32(mailbox, need, s);
+    if (e != VFX_OK) return e;
     hipLaunchKernelGGL(gru2_kernel, dim3(B * 4), dim3(512), 0, s, gi, whh_t, bhh, (float*)out->ptr, out->bstride,
                        out->cstride, T, (u64*)mailbox, (int*)err_flag, (const int*)out->rows);
     VFX_LAUNCHED();

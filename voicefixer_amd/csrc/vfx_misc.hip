@@ -374,6 +374,24 @@ extern "C" int vfx_mel_to_cond_rows_f32(const float* mel, const vfx_tensor* cond
 // --------------------------------------------------------------------------------------
 // peak rule + centre trim
 // --------------------------------------------------------------------------------------
+// Zeroing by a KERNEL, not hipMemsetAsync (round 4).  With hipMemsetAsync the peak workspace and the GRU mailboxes became memset
+// NODES of a captured HIP graph (Pipeline.enable_graphs), and this sequence then went wrong reproducibly on ROCm 7.0 / torch 2.10:
+// capture, two good replays, ONE eager pass of the same shape on the same stream (which issues its own memsets and makes torch
+// allocate new segments), and every later replay returned the waveform divided by ~3 -- the peak rule saw a stale workspace
+// (tools/dev/graph_retry_diag.py; found by tests/test_api_gpu.py::test_gru_retry_with_graphs_enabled_runs_eager in an order the
+// full suite does not run it in).  Memset nodes on their own replay correctly (checked in isolation), so the mechanism is not
+// established; with the zeroing as an ordinary kernel node the sequence is bit-exact again, and an eager launch costs the same.
+__global__ void zero_u32_kernel(uint32_t* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+int vfx_zero_u32(void* p, size_t bytes, hipStream_t s) {
+    const size_t n = (bytes + 3) / 4;
+    if (n == 0) return VFX_OK;
+    const unsigned blocks = (unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(zero_u32_kernel, dim3(blocks), dim3(256), 0, s, (uint32_t*)p, n);
+    return vfx_last_error();
+}
+
 __global__ __launch_bounds__(256) void peak_kernel(const float* __restrict__ y, long long y_bs, int Ly0,
                                                    uint32_t* __restrict__ peak, const int* __restrict__ ly_rows) {
     const int b = blockIdx.y;
@@ -411,8 +429,8 @@ __global__ __launch_bounds__(256) void trim_kernel(const float* __restrict__ y, 
 extern "C" int vfx_peak_f32(const float* y, int64_t y_bstride, int Ly, int B, uint32_t* peak, vfx_stream_t stream) {
     if (!y || !peak || B <= 0 || Ly <= 0 || B > 65535) return VFX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(peak, 0, sizeof(uint32_t) * B, s);
-    if (e != hipSuccess) return (int)e;
+    int e = vfx_zero_u32(peak, sizeof(uint32_t) * B, s);
+    if (e != VFX_OK) return e;
     int nb = (Ly + 255) / 256;
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak, (const int*)nullptr);
@@ -424,8 +442,8 @@ extern "C" int vfx_post_f32(const float* y, int64_t y_bstride, int Ly, float* ou
                             uint32_t* peak_ws, vfx_stream_t stream) {
     if (!y || !out || !peak_ws || B <= 0 || N <= 0 || Ly < N || B > 65535) return VFX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(peak_ws, 0, sizeof(uint32_t) * B, s);
-    if (e != hipSuccess) return (int)e;
+    int e = vfx_zero_u32(peak_ws, sizeof(uint32_t) * B, s);
+    if (e != VFX_OK) return e;
     int nb = (Ly + 255) / 256;
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws, (const int*)nullptr);
@@ -444,8 +462,8 @@ extern "C" int vfx_post_rows_f32(const float* y, int64_t y_bstride, int Ly, cons
                                  vfx_stream_t stream) {
     if (!y || !out || !peak_ws || !n_rows || B <= 0 || n_max <= 0 || Ly < n_max || B > 65535) return VFX_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(peak_ws, 0, sizeof(uint32_t) * B, s);
-    if (e != hipSuccess) return (int)e;
+    int e = vfx_zero_u32(peak_ws, sizeof(uint32_t) * B, s);
+    if (e != VFX_OK) return e;
     int nb = (Ly + 255) / 256;
     if (nb > 256) nb = 256;
     hipLaunchKernelGGL(peak_kernel, dim3(nb, B), dim3(256), 0, s, y, (long long)y_bstride, Ly, peak_ws,

@@ -598,7 +598,7 @@ class Pipeline:
     # ---- HIP-graph replay for repeated (batch, length) shapes --------------------------------------------------
     def enable_graphs(self, max_shapes=4, max_batch=4):
         """Opt in: ``restore`` of a (B <= max_batch, N) shape seen before replays ONE captured HIP graph of its ~300
-        kernel launches (plus memset nodes) instead of issuing them one by one from Python.  The graph owns its
+        kernel launches instead of issuing them one by one from Python.  The graph owns its
         intermediate buffers (torch's graph-private pool: ~0.4 GB per utterance of 10 s), so at most ``max_shapes``
         shapes are kept (least recently used first out).  Results are bit-identical to the eager path.  Meant for
         latency-sensitive small batches (single utterances, equal-length streaming chunks); at batch 32 the launches
@@ -607,7 +607,22 @@ class Pipeline:
         self._graph_cap = (int(max_shapes), int(max_batch))
 
     def disable_graphs(self):
+        self._drop_graphs(None)
         self._graphs = None
+
+    def _drop_graphs(self, key):
+        """Destroy one captured graph (``key``) or all of them (None).  Destroying a graph releases its private memory pool; the
+        device is drained first so that nothing queued can still be reading from it (graph destruction is rare: disable, eviction
+        of the least recently used shape)."""
+        graphs = getattr(self, "_graphs", None)
+        if not graphs:
+            return
+        torch.cuda.synchronize(self.device)
+        if key is None:
+            graphs.clear()
+        else:
+            graphs.pop(key, None)
+        torch.cuda.synchronize(self.device)
 
     def _capture(self, B, N):
         dev = self.device
@@ -642,7 +657,7 @@ class Pipeline:
             ent = graphs.pop(key, None)
             if ent is None:
                 while len(graphs) >= self._graph_cap[0]:
-                    graphs.pop(next(iter(graphs)))
+                    self._drop_graphs(next(iter(graphs)))
                 ent = self._capture(*key)
             graphs[key] = ent  # most recently used last
             g, static_in, static_out, last_use = ent
