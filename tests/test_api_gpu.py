@@ -853,7 +853,18 @@ def test_cli_folder_under_the_launcher_on_rccl(vf, seeded_states, tmp_path, monk
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "rank 0: 5 files" in r.stdout and "whole job: 5 files" in r.stdout and "on 1 GPU(s)" in r.stdout
-    for out in ("plain", "ranked"):
+    # (c) TWO ranks on the real device path: both ranks share this box's one GPU (LOCAL_RANK % device_count), so the counter exchange
+    # runs on gloo (RCCL refuses two ranks on one device) -- everything else is the product path: each rank restores the files
+    # dist.deal_files deals it with the real kernels, the union equals the unsharded folder
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port + 1), "-m", "voicefixer_amd", "-ifdr", str(ind), "-ofdr", str(tmp_path / "two"),
+                        "--gpus", "2", "--batch-size", "2", "--dist-backend", "gloo"], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rank 0:" in r.stdout and "rank 1:" in r.stdout and "whole job: 5 files" in r.stdout and "on 2 GPU(s)" in r.stdout
+    counts = [int(m) for m in __import__("re").findall(r"rank \d: (\d+) files", r.stdout)]
+    assert sorted(counts) in ([2, 3],) and sum(counts) == 5
+    for out in ("plain", "ranked", "two"):
         assert sorted(os.listdir(tmp_path / out)) == sorted(os.listdir(tmp_path / "want"))
         for f in os.listdir(tmp_path / "want"):
             x1, x2 = wavfile.read(str(tmp_path / out / f))[1], wavfile.read(str(tmp_path / "want" / f))[1]
