@@ -85,6 +85,10 @@ import os as _os
 # development switches: VFX_FUSE=0 runs every ResStack layer as two launches, VFX_CONVW=0 (read by the library)
 # keeps every launch on the first-generation kernel
 _FUSE = _os.environ.get("VFX_FUSE", "1") != "0"
+# The C = 64 layers with dilation >= 81 run as TWO Winograd F(4,3) launches (convwg4_kernel), in place, instead of the fused layer whose dilated
+# half is a direct sum there (a block of 4 d positions does not fit its tile): 18 GB instead of 10 GB through HBM per layer, but half the
+# products in the dilated half -- step 219.2 -> 217.6 ms alternating on one box (VFX_UNFUSE_WIDE=0 restores the fused form).
+_UNFUSE_WIDE = _os.environ.get("VFX_UNFUSE_WIDE", "1") != "0"
 FUSE_MAX_C = 128  # ResStack stages with at most this many channels CAN run one fused launch per layer
 # ResStack stages with at least this many channels run their two k = 3 convolutions per layer as two Winograd F(4,3)
 # launches (convwg4_kernel: half the fp32 MFMAs of the direct sum; the dilation-1 one moves its quads as 16-byte
@@ -217,9 +221,11 @@ class VocoderEngine:
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
+            unfused_from = None
             for i, (w1, w1d, b1, w2, w2d, b2, w2g, w1g4, w2g4) in enumerate(layers):
                 last = i == len(layers) - 1
-                if fused:
+                if fused and not (_UNFUSE_WIDE and c == 64 and 3 ** i > 27 and i % 2 == 0 and w1g4 is not None and _ARITH["winograd"]
+                                  and i + 1 < len(layers)) and not (unfused_from is not None and i >= unfused_from):
                     # one launch per layer, intermediate tile in LDS; input and output ping-pong between xs and ys
                     # (a tile reads its neighbours' input columns, so the update cannot be in place)
                     post, pslope = POST_NONE, 0.0
@@ -229,11 +235,13 @@ class VocoderEngine:
                     ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=_wg(w2g), w2g4=_wg(w2g4),
                                  w1g4=_wg(w1g4))
                     continue
-                if not wino:
+                if fused and unfused_from is None:
+                    unfused_from = i      # from the first widely dilated layer on: two F(4,3) launches per layer, in place on xs
+                if not wino and not fused:
                     w1g4 = w2g4 = None
-                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg4=w1g4)
+                ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg4=_wg(w1g4))
                 act = self.act_none if not last else (self.act_last if j == nst - 1 else self.act_last_snake)
-                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg4=w2g4)  # residual updated in place
+                ops.conv1d(ys, w2, b2, xs, Lo, 3, 1, PAD_ZERO, act, res=xs, w3=self._x3(w2), wd=w2d, wg4=_wg(w2g4))  # residual updated in place
             assert len(layers) % 2 == 0  # the fused ping-pong ends in xs
             h = xs
             L = Lo
