@@ -350,4 +350,4 @@ def test_selfcheck_default_direct_bf16x3_agree_stage_by_stage(pipe):
     finally:
         ops.PROFILE = None
         engine.set_winograd(True)
-    assert not ({80, 88, 91, 92, 94, 71, 72, 74} & direct_codes) and 80 in wino_codes and (wino_codes & {88, 91, 92, 94})
+    assert not ({80, 88, 91, 92, 94, 96, 71, 72, 74} & direct_codes) and 80 in wino_codes and (wino_codes & {88, 91, 92, 94, 96})
