@@ -344,6 +344,12 @@ class VoiceFixer(nn.Module):
         from . import ops
         tag, kind, host, lens = item
         lens = list(lens)
+        if kind not in ("ragged", "samples") or len(lens) != host.shape[0] or max(lens) > host.shape[1]:
+            raise ValueError("restore_batches: item must be (tag, 'ragged' | 'samples', host (B, >= max(lens)), lens (B))")
+        if kind == "ragged" and your_vocoder_func is not None:
+            raise ValueError("restore_batches: a plugin vocoder takes 'samples' batches (equal lengths); plan_batches(ragged=False) cuts them")
+        if kind == "samples" and min(lens) != max(lens):
+            raise ValueError("restore_batches: a 'samples' batch holds rows of ONE length")
         with torch.cuda.stream(stream):
             seg = host.to(pipe.device, non_blocking=True)
             if kind == "ragged":
