@@ -371,3 +371,23 @@ def test_restore_folder_host_pipeline_with_a_stub_device(tmp_path):
         assert y.shape == (want[nm[0]],) and np.abs(y).max() > 0.05
     a_in = audio_io.load_wav(str(ind / "a.wav"))
     assert np.abs(audio_io.load_wav(str(outd / "a-mode0.wav")) - a_in).max() <= 1.0 / 32768     # identity through PCM16
+
+
+def test_selfcheck_compare_and_report_on_made_up_stages(capsys):
+    """voicefixer_amd/selfcheck.py, host logic only: per-stage figures are relative to the DIRECT variant's own peak, the waveform
+    also gets an RMS line, and a stage above the tolerance is reported (and named) as a failure."""
+    import io
+    from voicefixer_amd import selfcheck
+    g = torch.Generator().manual_seed(0)
+    base = {k: torch.randn(2, 5, 7, generator=g, dtype=torch.float64) for k in selfcheck.STAGES}
+    same = {k: v.clone() for k, v in base.items()}
+    off = {k: v.clone() for k, v in base.items()}
+    off["up3"][0, 0, 0] += 1e-3 * float(base["up3"].abs().max())
+    rows = selfcheck.compare(off, base)
+    assert abs(rows["up3"] - 1e-3) < 1e-9 and rows["up2"] == 0.0 and rows["wav_rms"] == 0.0
+    buf = io.StringIO()
+    bad, table = selfcheck.report({"default": same, "direct": base, "bf16x3": off}, 1e-4, out=buf)
+    assert [(v, k) for v, k, _ in bad] == [("bf16x3", "up3")] and set(table) == {"default", "bf16x3"}
+    assert "above 1e-04" in buf.getvalue() and buf.getvalue().count("\n") == len(selfcheck.STAGES) + 2
+    bad, _ = selfcheck.report({"default": same, "direct": base}, 1e-4, out=io.StringIO())
+    assert bad == []
