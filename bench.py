@@ -236,13 +236,16 @@ def scatter_job(args, pipe, n, rank, world, dev, dist):
     dist.destroy_process_group()
 
 
-def folder_job(args, rank, world, dev, dist):
+def folder_job(args, rank, world, dev, dist, dry=False):
     """BASELINE configs[2] / [3] as the PRODUCT runs them, disk to disk: a folder of ``--synth-folder`` x world synthetic
     utterances (PCM16 WAV on tmpfs; or ``--folder DIR``) goes through ``VoiceFixer.restore_folder`` -- every rank lists
     the folder, takes the files dist.deal_files deals it, decodes / restores / encodes them (ragged batches of
     ``--batch``) and writes its outputs; no data-path collective, one all-gather of per-rank counters.  Timed from the
     folder on disk to the last output file closed, barrier + max over ranks; beside it, in the same process, the
-    HBM-resident rate of the headline bench (``hbm_resident``) so that the two can be divided."""
+    HBM-resident rate of the headline bench (``hbm_resident``) so that the two can be divided.
+    ``dry`` (``--dry-run``, tests/test_bench_launcher.py): the same job on CPU with the DEVICE STAGE replaced by the identity and gloo
+    instead of RCCL -- folder preparation by rank 0, the barriers, the deal, decode / encode workers, the all-gather of the counters and
+    the JSON line are the real code."""
     import shutil
     import numpy as np
     from voicefixer_amd import weights, audio_io, dist as vdist
@@ -271,13 +274,26 @@ def folder_job(args, rank, world, dev, dist):
         ind = args.folder
 
     def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+        if not dry:
             torch.cuda.synchronize()
+        if dist is not None and dist.is_initialized():
+            dist.barrier()
+            if not dry:
+                torch.cuda.synchronize()
 
-    vf = VoiceFixer.from_state(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321))
-    pipe = vf._get_pipe()
+    if dry:
+        class _StubDevice(VoiceFixer):        # test hook: no checkpoints, no device -- the device stage hands the rows back
+            def __init__(self):
+                pass
+
+            def restore_batches(self, batches, your_vocoder_func=None, streams=2, mode=0):
+                for tag, kind, host, lens in batches:
+                    yield tag, host.clone(), list(lens)
+
+        vf, pipe = _StubDevice(), None
+    else:
+        vf = VoiceFixer.from_state(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321))
+        pipe = vf._get_pipe()
     barrier()      # (rank 0 has written the folders)
     ext = (".wav", ".flac") if args.folder else (".wav",)
     vf.restore_folder(warm_in, warm_out, batch_size=args.batch, io_threads=args.io_threads, rank=rank, world=world, extensions=ext)
@@ -289,17 +305,20 @@ def folder_job(args, rank, world, dev, dist):
     barrier()
     dt = time.perf_counter() - t0
     # the HBM-resident rate of the same build in the same process (one stream, no per-launch events): bench.py's headline loop
-    x = synth_batch(args.batch, n, 1000 + rank, dev)
-    pipe.restore(x, n)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(max(2, args.steps)):
+    hbm_ms = float("nan")
+    if not dry:
+        x = synth_batch(args.batch, n, 1000 + rank, dev)
         pipe.restore(x, n)
-    torch.cuda.synchronize()
-    hbm_ms = (time.perf_counter() - t1) / max(2, args.steps) * 1e3
-    pipe.check()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(2, args.steps)):
+            pipe.restore(x, n)
+        torch.cuda.synchronize()
+        hbm_ms = (time.perf_counter() - t1) / max(2, args.steps) * 1e3
+        pipe.check()
     keys = ["files", "audio_s", "wall_s", "decode_worker_s", "encode_worker_s", "device_waited_for_decode_s", "batches"]
-    allr = vdist.gather_counters([st[k] for k in keys] + [dt, hbm_ms, float(dev.index)], dev if dist is not None else None)
+    allr = vdist.gather_counters([st[k] for k in keys] + [dt, 0.0 if dry else hbm_ms, float(dev.index) if dev is not None else -1.0],
+                                 dev if (dist is not None and not dry) else None)
     if rank == 0:
         outs = sorted(os.listdir(outd))
         assert len(outs) == int(sum(x[0] for x in allr)) == st["folder_files"], (len(outs), st["folder_files"])
@@ -307,7 +326,7 @@ def folder_job(args, rank, world, dev, dist):
         assert np.isfinite(y).all() and np.abs(y).max() > 1e-3
         dmax = max(x[7] for x in allr)
         audio = sum(x[1] for x in allr)
-        hbm_value = world * args.batch * args.seconds / (max(x[8] for x in allr) * 1e-3)
+        hbm_value = None if dry else world * args.batch * args.seconds / (max(x[8] for x in allr) * 1e-3)
         line = {
             "metric": "seconds-of-44.1kHz-audio restored per wall-second",
             "value": round(audio / dmax, 2), "unit": "x real-time", "n_gpus": world,
@@ -322,21 +341,22 @@ def folder_job(args, rank, world, dev, dist):
                        "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "io_threads": args.io_threads,
                        "streams": args.folder_streams, "host_cores": os.cpu_count(), "folder": base if synthetic else args.folder,
                        "parallelism": "files dealt to %d rank(s) by dist.deal_files (no data-path collective; one all-gather of counters)" % world},
-            "hbm_resident": {"value": round(hbm_value, 2), "ms_per_step": round(max(x[8] for x in allr), 3)},
-            "disk_to_disk_over_hbm_resident": round(audio / dmax / hbm_value, 4),
+            "hbm_resident": None if dry else {"value": round(hbm_value, 2), "ms_per_step": round(max(x[8] for x in allr), 3)},
+            "disk_to_disk_over_hbm_resident": None if dry else round(audio / dmax / hbm_value, 4),
             "decode_worker_s": round(sum(x[3] for x in allr), 3), "encode_worker_s": round(sum(x[4] for x in allr), 3),
             "decode_x_realtime_per_thread": round(audio / max(sum(x[3] for x in allr), 1e-9), 1),
             "encode_x_realtime_per_thread": round(audio / max(sum(x[4] for x in allr), 1e-9), 1),
             "requested_gpus": int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus)), "visible_devices": torch.cuda.device_count(),
-            "rccl": {"backend": dist.get_backend() if dist is not None else None, "world_size": world},
-            "per_rank": [{"rank": r, "device": "cuda:%d" % int(x[9]), "files": int(x[0]), "audio_s": round(x[1], 1), "batches": int(x[6]),
+            "rccl": {"backend": dist.get_backend() if (dist is not None and dist.is_initialized()) else None, "world_size": world},
+            **({"dry_run": True} if dry else {}),
+            "per_rank": [{"rank": r, "device": "dry" if dry else "cuda:%d" % int(x[9]), "files": int(x[0]), "audio_s": round(x[1], 1), "batches": int(x[6]),
                           "wall_s": round(x[7], 4), "folder_s": round(x[2], 4), "decode_worker_s": round(x[3], 3),
                           "encode_worker_s": round(x[4], 3), "device_waited_for_decode_s": round(x[5], 4)} for r, x in enumerate(allr)],
-            "lib_build_id": _lib_build_id(),
+            "lib_build_id": None if dry else _lib_build_id(),
         }
         _json_line_last(line)
         shutil.rmtree(base, ignore_errors=True)
-    if dist is not None:
+    if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -384,6 +404,8 @@ def dry_run(args, rank, world):
     import torch.distributed as dist
     if world > 1:
         dist.init_process_group(backend="gloo")
+    if args.synth_folder or args.folder:      # the folder job with a stub device stage (see folder_job)
+        return folder_job(args, rank, world, None, dist, dry=True)
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     dt = torch.tensor([time.perf_counter() - t0, float(rank)], dtype=torch.float64)

@@ -44,3 +44,16 @@ def test_under_an_external_launcher_the_script_does_not_relaunch():
 def test_gpus_flag_is_read():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "args.gpus" in src and "torch.distributed.run" in src
+
+
+def test_folder_job_on_two_ranks_with_a_stub_device_stage():
+    """``bench.py --gpus 2 --synth-folder F`` (BASELINE configs[3] disk to disk) rehearsed on CPU: the self-launch, rank 0 writing the
+    synthetic folder, the barriers, dist.deal_files, the decode / encode workers of restore_folder, the all-gather of the per-rank
+    counters and the JSON line are the real code; only the device stage is a stub (identity) and RCCL is gloo."""
+    line, _ = _run("--gpus", "2", "--synth-folder", "5", "--seconds", "0.25", "--batch", "4", "--io-threads", "2")
+    assert line["dry_run"] is True and line["n_gpus"] == 2 and line["rccl"] == {"backend": "gloo", "world_size": 2}
+    files = [r["files"] for r in line["per_rank"]]
+    assert sum(files) == 10 and files == [5, 5] and [r["rank"] for r in line["per_rank"]] == [0, 1]
+    assert abs(sum(r["audio_s"] for r in line["per_rank"]) - 10 * 0.25) < 0.11 and line["value"] > 0
+    assert all(r["decode_worker_s"] > 0 and r["encode_worker_s"] > 0 and r["batches"] == 2 for r in line["per_rank"])
+    assert "configs[3]" in line["config"]["workload"] and line["hbm_resident"] is None
