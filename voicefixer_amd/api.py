@@ -357,7 +357,10 @@ class VoiceFixer(nn.Module):
                     if min(lens) < 1536:
                         raise VfxError("mode 1 shortens a file to 512 * (n // 512) samples: %d samples leave too few for the "
                                        "reflect-padded STFT (needs > 1024 after the cut)" % min(lens))
-                    cut = torch.zeros_like(seg)
+                    new_lens = [512 * (n // 512) for n in lens]
+                    # (rows are written in place into ONE buffer of exactly the width the longest cut row needs; what lies behind a
+                    # row's own end is never read -- every kernel takes the per-row lengths -- so it is not cleared)
+                    cut = torch.empty((len(lens), max(new_lens)), dtype=torch.float32, device=seg.device)
                     done = {}
                     for r in range(len(lens)):           # the cut-off is a per-file quantity (base.py:87-104);
                         if r in done:                    # rows of EQUAL length share one launch (vfx_hf_cut_f32 takes B rows)
@@ -372,8 +375,8 @@ class VoiceFixer(nn.Module):
                                 cut[q, :y.shape[1]] = y[0]
                         for q in same:
                             done[q] = True
-                    lens = [512 * (n // 512) for n in lens]
-                    seg = cut[:, :max(lens)].contiguous()
+                    lens = new_lens
+                    seg = cut
                 full = pipe.restore_rows(seg, lens)
                 lens_out = lens
             else:
