@@ -201,3 +201,169 @@ def test_restore_folder_explicit_rank_and_world_without_a_process_group(tmp_path
     assert not (set(a) & set(b)) and set(a) | set(b) == set(lens)
     with pytest.raises(ValueError):
         Stub().restore_folder(ind, outd, rank=2, world=2)
+
+
+# ---- per-file fault isolation and resume of the (sharded) folder job ----
+
+def _add_bad_files(ind):
+    """Four inputs a folder job must survive: a RIFF header cut off before its data chunk, a 500-sample file, a file whose
+    header parses but whose decoder raises (a format tag scipy refuses), and a PCM16 file whose data chunk holds fewer
+    samples than its header promises (an interrupted recording: restored at the length that is really there)."""
+    import struct
+    import numpy as np
+    from scipy.io import wavfile
+    with open(os.path.join(ind, "bad_header.wav"), "wb") as f:
+        f.write(b"RIFF\x24\x00\x00\x00WAVEfmt ")
+    wavfile.write(os.path.join(ind, "bad_short.wav"), 44100, (1000 * np.sin(np.arange(500) * 0.1)).astype(np.int16))
+    n = 3000
+    fmt = struct.pack("<HHIIHH", 0x0002, 1, 44100, 44100 * 2, 2, 16)      # ADPCM tag: wav_length reads it, scipy raises
+    with open(os.path.join(ind, "bad_decode.wav"), "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + 2 * n) + b"WAVE" + b"fmt " + struct.pack("<I", 16) + fmt +
+                b"data" + struct.pack("<I", 2 * n) + bytes(2 * n))
+    x = (2000 * np.sin(np.arange(4000) * 0.02)).astype(np.int16)
+    wavfile.write(os.path.join(ind, "truncated.wav"), 44100, x)
+    raw = open(os.path.join(ind, "truncated.wav"), "rb").read()
+    with open(os.path.join(ind, "truncated.wav"), "wb") as f:
+        f.write(raw[:44 + 2 * 2900])            # header still says 4000 samples, 2900 are there
+    return {"bad_header.wav", "bad_short.wav", "bad_decode.wav"}, {"truncated.wav": 2900}
+
+
+def _faulty_worker(rank, world, port, ind, outd, q, use_cli):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import warnings
+    warnings.simplefilter("ignore")          # (scipy warns about the truncated data chunk)
+    from voicefixer_amd import api
+
+    class Stub(_StubDevice, api.VoiceFixer):
+        pass
+
+    if use_cli:
+        import contextlib
+        import io
+        from voicefixer_amd import __main__ as cli
+        api.VoiceFixer = Stub
+        err = io.StringIO()
+        with contextlib.redirect_stderr(err):
+            rc = cli.main(["-ifdr", ind, "-ofdr", outd, "--gpus", str(world), "--dist-backend", "gloo", "--batch-size", "4"])
+        q.put((rank, rc, err.getvalue()))
+        return
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st = {}
+        names = Stub().restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st)
+        every = vdist.gather_objects((st["failed"], st["truncated"]))       # the collective after the job: nobody hangs
+        vdist.gather_counters([st["files"], st["audio_s"]])
+        q.put((rank, names, every))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_cli", [False, True])
+def test_folder_job_survives_bad_files_on_two_ranks(tmp_path, use_cli):
+    """One truncated header, one 500-sample file, one file that fails in the decoder, one file shorter than its header says:
+    every OTHER output is written exactly once, the short-data file is restored at its real length, the three bad ones are
+    listed with a reason (each by exactly one rank), both ranks reach the collectives, the CLI exits with status 2."""
+    import numpy as np
+    from voicefixer_amd import audio_io
+    ind, outd = str(tmp_path / "in"), str(tmp_path / "out")
+    lens = _make_ragged_folder(ind, 19, seed=5)
+    bad, trunc = _add_bad_files(ind)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_faulty_worker, args=(r, 2, port, ind, outd, q, use_cli)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    good = dict(lens, **trunc)
+    assert sorted(os.listdir(outd)) == sorted(good)             # (no .part-* leftovers either)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for name, n in good.items():
+            y, x = audio_io.load_wav(os.path.join(outd, name)), audio_io.load_wav(os.path.join(ind, name))
+            assert y.shape == (n,) and x.shape == (n,) and np.abs(y + x).max() <= 1.0 / 32768 + 1e-7, name
+    if use_cli:
+        assert [g[1] for g in got] == [2, 2]
+        for name in bad:
+            assert "FAILED %s" % name in got[0][2] and "FAILED %s" % name not in got[1][2]    # rank 0 speaks for the job, once per file
+        assert "3 file(s) failed" in got[0][2]
+        return
+    a, b = set(got[0][1]), set(got[1][1])
+    assert not (a & b) and a | b == set(good)
+    assert got[0][2] == got[1][2]
+    failed = [f for fs, _ in got[0][2] for f in fs]
+    assert sorted(n for n, _ in failed) == sorted(bad)
+    why = dict(failed)
+    assert "data chunk" in why["bad_header.wav"] and "too short" in why["bad_short.wav"] and why["bad_decode.wav"]
+    assert [t for _, ts in got[0][2] for t in ts] == [("truncated.wav", 4000, 2900)]
+
+
+def test_a_failing_batch_is_reissued_row_by_row(tmp_path):
+    """The device stage raises for every batch that contains file `utt003` and for that file alone: the rows that shared
+    its batch (and the batches in flight behind it) are still written, utt003 is listed with the device's reason."""
+    from voicefixer_amd import api
+
+    class Refuses(api.VoiceFixer):
+        calls = []
+
+        def __init__(self):
+            pass
+
+        def restore_batches(self, batches, your_vocoder_func=None, streams=2, mode=0):
+            held = []
+            for tag, kind, host, lens in batches:           # one batch 'in flight' behind the one that is finished,
+                held.append((tag, host, lens))              # as the real generator keeps them
+                if len(held) > 1:
+                    t, h, l = held.pop(0)
+                    Refuses.calls.append(list(t))
+                    if 3 in t:
+                        raise RuntimeError("vfx_conv1d_f32 failed with code 1")
+                    yield t, -h, list(l)
+            for t, h, l in held:
+                Refuses.calls.append(list(t))
+                if 3 in t:
+                    raise RuntimeError("vfx_conv1d_f32 failed with code 1")
+                yield t, -h, list(l)
+
+    ind, outd = str(tmp_path / "in"), str(tmp_path / "out")
+    lens = _make_ragged_folder(ind, 13, seed=2)
+    st = {}
+    names = Refuses().restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st)
+    assert sorted(names) == sorted(n for n in lens if n != "utt003.wav") == sorted(os.listdir(outd))
+    assert st["failed"] == [("utt003.wav", "RuntimeError: vfx_conv1d_f32 failed with code 1")]
+    assert [3] in Refuses.calls and st["files"] == 12
+
+
+def test_skip_existing_resumes_a_folder_job(tmp_path):
+    from voicefixer_amd import api
+
+    class Stub(_StubDevice, api.VoiceFixer):
+        pass
+
+    ind, outd = str(tmp_path / "in"), str(tmp_path / "out")
+    lens = _make_ragged_folder(ind, 9, seed=4)
+    assert len(Stub().restore_folder(ind, outd, batch_size=4, io_threads=2)) == 9
+    for gone in ("utt002.wav", "utt007.wav"):
+        os.remove(os.path.join(outd, gone))
+    before = {n: os.stat(os.path.join(outd, n)).st_mtime_ns for n in os.listdir(outd)}
+    st = {}
+    again = Stub().restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st, skip_existing=True)
+    assert again == ["utt002.wav", "utt007.wav"] and len(st["skipped"]) == 7 and st["failed"] == []
+    assert all(os.stat(os.path.join(outd, n)).st_mtime_ns == t for n, t in before.items())
+    assert sorted(os.listdir(outd)) == sorted(lens)
+    # two ranks, sequentially, second look at a folder the first already wrote into: the deal does not depend on the outputs
+    for gone in ("utt001.wav", "utt002.wav", "utt003.wav", "utt004.wav"):
+        os.remove(os.path.join(outd, gone))
+    a = Stub().restore_folder(ind, outd, batch_size=4, io_threads=2, rank=0, world=2, skip_existing=True)
+    b = Stub().restore_folder(ind, outd, batch_size=4, io_threads=2, rank=1, world=2, skip_existing=True)
+    assert sorted(a + b) == ["utt001.wav", "utt002.wav", "utt003.wav", "utt004.wav"]
+
+
+def test_io_thread_default_and_cpu_slices():
+    assert vdist.default_io_threads(1, cores=128) == 8 and vdist.default_io_threads(8, cores=128) == 8
+    assert vdist.default_io_threads(8, cores=64) == 4 and vdist.default_io_threads(8, cores=8) == 2
+    assert vdist.pin_rank_cpus(0, 1) is None

@@ -18,7 +18,10 @@ Differences, all deliberate:
   * ``--selfcheck [IN.wav]`` (extension): runs the input through the path with the default (Winograd), the direct and the
     opt-in bf16x3 arithmetic and compares them stage by stage (voicefixer_amd/selfcheck.py) -- the one-command check for
     users with real checkpoints;
-  * output formats are WAV and FLAC (``audio_io.FORMATS``) instead of whatever libsndfile offers.
+  * output formats are WAV and FLAC (``audio_io.FORMATS``) instead of whatever libsndfile offers;
+  * folder mode isolates faults per FILE: an unreadable / truncated / too short input or a row the device refuses costs that
+    file only -- it is listed on stderr with its reason, every other file is written, the exit status is 2 (all ranks of a
+    ``--gpus N`` job learn the list through one all-gather and none of them hangs); ``--skip-existing`` resumes a job.
 """
 import argparse
 import os
@@ -95,6 +98,11 @@ def build_parser():
                         help="(extension) folder mode: shard the folder over this many GPUs (one process per GPU, self-launched)")
     parser.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                         help="(extension) torch.distributed backend of the per-rank counter exchange (nccl == RCCL)")
+    parser.add_argument("--skip-existing", default=False, action="store_true",
+                        help="(extension) folder mode: leave files whose output already exists alone (resume an interrupted job; "
+                             "outputs are written under a temporary name and renamed, so an existing output is a complete one)")
+    parser.add_argument("--io-threads", type=int, default=0,
+                        help="(extension) folder mode: decode / encode workers per rank (default: host cores / (2 * ranks), 2..8)")
     return parser
 
 
@@ -110,6 +118,17 @@ def folder_ranks(args, argv):
               % (args.gpus, visible, nproc), file=sys.stderr, flush=True)
     if nproc > 1:
         vdist.exec_ranks(nproc, ["-m", "voicefixer_amd"] + list(argv))
+
+
+def report_failures(failed, skipped, silent):
+    """The per-file outcome of a folder job that the counters do not carry: files that were given up on (ALWAYS printed, to
+    stderr: the exit status 2 needs its reasons) and, unless ``--silent``, how many existing outputs ``--skip-existing`` left alone."""
+    if skipped and not silent:
+        print("skipped %d file(s) whose output already exists" % len(skipped))
+    for name, why in failed:
+        print("voicefixer_amd: FAILED %s: %s" % (name, why), file=sys.stderr, flush=True)
+    if failed:
+        print("voicefixer_amd: %d file(s) failed; every other file was written" % len(failed), file=sys.stderr, flush=True)
 
 
 def report_ranks(per_rank, silent):
@@ -161,6 +180,8 @@ def main(argv=None):
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
         tdist.init_process_group(backend=args.dist_backend)
+        from . import dist as vdist
+        vdist.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         if rank != 0:
             args.silent = True        # rank 0 speaks for the job
             process_file = False      # a single file is one rank's work
@@ -177,6 +198,7 @@ def main(argv=None):
     if process_file:
         for m in modes:
             writefile(voicefixer, args.infile, args.outfile, m, append, cuda, verbose=not args.silent)
+    n_failed = 0
     if process_folder:
         n_files = len([f for f in os.listdir(args.infolder) if os.path.splitext(os.path.basename(f))[-1] == ".wav"])
         if not args.silent:
@@ -185,23 +207,39 @@ def main(argv=None):
         for m in modes:
             start = time.time()
             st = {}
-            voicefixer.restore_folder(args.infolder, args.outfolder, mode=m, batch_size=args.batch_size,
-                                      name_suffix="-mode%d" % m if append else "", stats=st)
+            try:
+                voicefixer.restore_folder(args.infolder, args.outfolder, mode=m, batch_size=args.batch_size,
+                                          name_suffix="-mode%d" % m if append else "", stats=st,
+                                          skip_existing=args.skip_existing, io_threads=args.io_threads or None)
+            except Exception as e:    # noqa: BLE001 -- per-file faults never get here (restore_folder isolates them); whatever does
+                # must not leave the other ranks waiting in the collectives below: this rank reports itself and goes on to them
+                import traceback
+                traceback.print_exc()
+                st.setdefault("failed", []).append(("<rank %d>" % rank, "%s: %s" % (type(e).__name__, e)))
+            for k in ("files", "audio_s", "wall_s", "decode_worker_s", "encode_worker_s", "device_waited_for_decode_s"):
+                st.setdefault(k, 0.0)
+            failed, skipped = list(st.get("failed", [])), list(st.get("skipped", []))
             if launched:
                 dev = torch.device("cuda", torch.cuda.current_device()) if args.dist_backend == "nccl" else None
                 per_rank = vdist.gather_counters([st["files"], st["audio_s"], st["wall_s"], st["decode_worker_s"],
                                                   st["encode_worker_s"], st["device_waited_for_decode_s"]], dev)
+                every = vdist.gather_objects((failed, skipped))      # names and reasons: every rank learns the job's outcome
+                failed = sorted(f for fs, _ in every for f in fs)
+                skipped = sorted(n for _, sk in every for n in sk)
                 if rank == 0:
                     report_ranks(per_rank, args.silent)
+            if rank == 0:
+                report_failures(failed, skipped, args.silent)
+            n_failed += len(failed)
             if not args.silent:
-                print("Restoration of %d files (mode %d) took %s s" % (n_files, m, round(time.time() - start, 1)))
+                print("Restoration of %d files (mode %d) took %s s" % (n_files - len(failed) - len(skipped), m, round(time.time() - start, 1)))
     if launched:
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
     if not args.silent:
         print("Done")
-    return 0
+    return 2 if n_failed else 0      # 2: the job ran to its end, every good file is written, some files were given up on (listed on stderr)
 
 
 if __name__ == "__main__":

@@ -416,7 +416,10 @@ class VoiceFixer(nn.Module):
         pipe.set_streams(len(pool))
         ok = False
         try:
-            pipe.check()                      # a flag that is already set belongs to an earlier, unchecked launch
+            try:
+                pipe.check()                  # a flag that is already set belongs to an earlier, unchecked launch (a direct
+            except GruHandoffMissed:          # pipe.restore user): check() has cleared it, and none of THIS call's work failed
+                pass
             nb = 0
 
             def finish_oldest():
@@ -546,8 +549,51 @@ class VoiceFixer(nn.Module):
             i += len(grp)
         return out[:, :n_out]
 
-    def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=8, your_vocoder_func=None,
-                       name_suffix="", extensions=(".wav",), rank=None, world=None, streams=2, ahead=3, stats=None):
+    MIN_SAMPLES = {0: 1025, 1: 1536}   # shortest restorable file: the reflect-padded STFT needs > 1024 samples (mode 1: after the cut to 512 * (n // 512))
+
+    def _restore_batches_isolated(self, items, failed, your_vocoder_func, streams, mode):
+        """``restore_batches`` with per-row fault isolation (the folder job's device stage): when a batch raises -- a
+        length a kernel refuses, an allocation that does not fit, a plugin vocoder error -- the batches that were in
+        flight are re-issued ROW BY ROW, every row that still fails is recorded as ``(tag, reason)`` in ``failed`` and
+        the stream of batches continues; the job loses the failing file, nothing else (the reference's serial loop,
+        voicefixer/__main__.py:187-212, keeps every file it finished before a bad one)."""
+        from collections import deque
+        src = iter(items)
+        pending = deque()
+
+        def feed():
+            for it in src:
+                pending.append(it)
+                yield it
+
+        while True:
+            try:
+                for tag, out_host, lens_out in self.restore_batches(feed(), your_vocoder_func, streams, mode):
+                    pending.popleft()
+                    yield tag, out_host, lens_out
+                return
+            except (KeyboardInterrupt, GeneratorExit):
+                raise
+            except Exception as exc:    # noqa: BLE001 -- whatever the batch raised costs the rows that raise it again, alone
+                bad = list(pending)
+                pending.clear()
+                if not bad:
+                    raise
+                first = "%s: %s" % (type(exc).__name__, exc)
+                for tag, kind, host, lens in bad:
+                    for r in range(len(tag)):
+                        one = (tag[r:r + 1], kind, host[r:r + 1, :max(int(lens[r]), 1)], [lens[r]])
+                        try:
+                            for t1, o1, l1 in self.restore_batches(iter([one]), your_vocoder_func, streams, mode):
+                                yield t1, o1, l1
+                        except (KeyboardInterrupt, GeneratorExit):
+                            raise
+                        except Exception as e1:    # noqa: BLE001
+                            failed.append((tag[r], "%s: %s" % (type(e1).__name__, e1) if str(e1) else first))
+
+    def restore_folder(self, infolder, outfolder, mode=0, batch_size=32, io_threads=None, your_vocoder_func=None,
+                       name_suffix="", extensions=(".wav",), rank=None, world=None, streams=2, ahead=3, stats=None,
+                       skip_existing=False):
         """Folder inference (the reference's CLI loop, voicefixer/__main__.py:176-212: every ``*.wav`` of
         ``infolder`` -> same file name in ``outfolder``), batched, pipelined and -- with ``world`` > 1 -- sharded over
         one process per GPU (BASELINE configs[2] and [3]).
@@ -562,19 +608,33 @@ class VoiceFixer(nn.Module):
         decode || restore || encode with the device never waiting.  No collective in the data path; every output file is
         written by exactly one rank.  ``rank`` / ``world`` default to the initialised ``torch.distributed`` group (or 0 / 1).
 
+        A bad file costs THAT file (the reference's loop keeps every file it finished before a bad one; a batched, sharded
+        job must not do worse): an unreadable header, a file too short to restore (< 1025 samples; mode 1: < 1536), a decode
+        error in a worker, a row the device stage refuses (its batch is re-issued row by row) -- each is skipped, recorded
+        as ``(file name, reason)`` in ``stats["failed"]`` and the job goes on; the header length only PLANS (staging
+        width, dealing): a truncated file is restored at the length the decoder really returned.  Outputs are written
+        to a temporary name and renamed, so a file in ``outfolder`` is always complete; ``skip_existing`` leaves files
+        whose output already exists alone (resume after an interrupted job; listed in ``stats["skipped"]``).
+
         ``mode`` 0 or 1 (restore_batch); ``name_suffix`` goes between base name and extension (the CLI's ``-mode<k>``
         naming for ``--mode all``).  ``extensions``: which files of the folder are taken -- the reference's loop takes
         ``.wav`` only (the default, and what the CLI passes); ``(".wav", ".flac")`` adds FLAC inputs, written back as
         FLAC (the workers decode / resample / encode in libvfx_audio.so, several thousand x real time).
+        ``io_threads``: decode / encode workers of this rank (default: the host's cores / (2 * world), 2..8).
         ``stats`` (optional dict) receives this rank's counters: files, audio seconds, wall seconds, summed worker
-        seconds of decode and encode, seconds the device stage waited for decoded input.
+        seconds of decode and encode, seconds the device stage waited for decoded input, ``failed``, ``skipped``.
         Returns the list of file names THIS rank wrote."""
         import threading
         import time
+        from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         from . import dist as vdist, flac
         self._check_mode(mode)
         rank, world = vdist.rank_world(rank, world)
+        if io_threads is None:
+            io_threads = vdist.default_io_threads(world)
+        io_threads = max(1, int(io_threads))
+        min_len = self.MIN_SAMPLES[mode]
         files = sorted(f for f in os.listdir(infolder) if os.path.splitext(f)[-1] in tuple(extensions))
         os.makedirs(outfolder, exist_ok=True)
         paths = [os.path.join(infolder, f) for f in files]
@@ -584,28 +644,71 @@ class VoiceFixer(nn.Module):
         t_start = time.perf_counter()
         lock = threading.Lock()
         cnt = {"decode_s": 0.0, "encode_s": 0.0, "stall_s": 0.0}
+        failed = []            # (index, reason): files this rank gave up on
+        real_len = {}          # index -> samples the decoder returned
+        truncated = []         # (index, header length, decoded length): restored at the decoded length
+
+        def scan(i):
+            """Planning length of file i from its header; None + reason when the header is unreadable.  A header that
+            promises less than a restorable file (0 in a streamed / interrupted recording) is not believed: the file
+            is decoded once to see what is really there."""
+            try:
+                n = audio_io.wav_length(paths[i], 44100)
+                if n < min_len:
+                    n = len(audio_io.load_wav(paths[i], 44100))
+                return n, None
+            except Exception as e:    # noqa: BLE001 -- any unreadable file is this file's problem only
+                return None, "%s: %s" % (type(e).__name__, e)
 
         def decode_into(i, row, n):
+            """Worker: file i -> staging row (width n = the header's promise).  Returns the number of samples really
+            there (<= n: a longer decode is cut at the staging width), or raises -- the caller drops the row."""
             t0 = time.perf_counter()
             x = audio_io.load_wav(paths[i], 44100)
-            if len(x) != n:
-                raise RuntimeError("%s: header promised %d samples at 44.1 kHz, decoder returned %d" % (paths[i], n, len(x)))
-            row[:n] = x
-            row[n:] = 0.0
+            m = min(len(x), n)
+            row[:m] = x[:m]
+            row[m:] = 0.0
             with lock:
                 cnt["decode_s"] += time.perf_counter() - t0
+                if len(x) != n:
+                    truncated.append((i, n, len(x)))
+            return m
 
         def encode_from(row, i):
             t0 = time.perf_counter()
-            audio_io.save_wave(row, os.path.join(outfolder, names[i]), 44100)
+            final = os.path.join(outfolder, names[i])
+            part = os.path.join(outfolder, ".part-%d-%s" % (os.getpid(), names[i]))   # (same extension: save_wave picks the container from it)
+            try:
+                audio_io.save_wave(row, part, 44100)
+                os.replace(part, final)
+            except BaseException:
+                if os.path.exists(part):
+                    os.remove(part)
+                raise
             with lock:
                 cnt["encode_s"] += time.perf_counter() - t0
 
-        written = []
-        with ThreadPoolExecutor(max_workers=max(1, io_threads)) as pool:
-            lengths = list(pool.map(lambda p: audio_io.wav_length(p, 44100), paths))
-            owner = vdist.deal_files(lengths, world)
-            mine = sorted((i for i in range(len(files)) if owner[i] == rank), key=lambda i: (lengths[i], i))
+        written, skipped, done = [], [], []
+        with ThreadPoolExecutor(max_workers=io_threads) as pool:
+            scanned = list(pool.map(scan, range(len(files))))
+            # every rank sees the same headers, so every rank drops the same files; each dropped file is REPORTED by one rank
+            usable = []
+            for i, (n, why) in enumerate(scanned):
+                if why is None and n < min_len:
+                    why = "too short to restore: %d samples at 44.1 kHz (mode %d needs >= %d)" % (n, mode, min_len)
+                if why is not None:
+                    if i % world == rank:
+                        failed.append((i, why))
+                else:
+                    usable.append(i)
+            lengths = {i: scanned[i][0] for i in usable}
+            owner = vdist.deal_files([lengths[i] for i in usable], world)
+            mine = sorted((i for i, o in zip(usable, owner) if o == rank), key=lambda i: (lengths[i], i))
+            if skip_existing:
+                # applied AFTER the deal and to this rank's own files only: the deal depends on nothing but the input headers,
+                # so ranks that look at the output folder at different moments still agree on who owns what
+                skipped = [names[i] for i in mine if os.path.exists(os.path.join(outfolder, names[i]))]
+                mine = [i for i in mine if not os.path.exists(os.path.join(outfolder, names[i]))]
             plan = plan_batches([lengths[i] for i in mine], batch_size, ragged=your_vocoder_func is None)
 
             def submit_decode(b):
@@ -623,24 +726,59 @@ class VoiceFixer(nn.Module):
                     if b + ahead < len(plan):
                         queue.append(submit_decode(b + ahead))
                     t0 = time.perf_counter()
-                    for f in futs:
-                        f.result()
+                    keep, real = [], []
+                    for r, f in enumerate(futs):
+                        try:
+                            m = f.result()
+                            if m < min_len:
+                                raise RuntimeError("too short to restore: the header promised %d samples, the decoder "
+                                                   "returned %d (mode %d needs >= %d)" % (lens[r], m, mode, min_len))
+                            keep.append(r)
+                            real.append(m)
+                            real_len[idx[r]] = m
+                        except Exception as e:    # noqa: BLE001 -- a decode error costs this file only
+                            failed.append((idx[r], "%s: %s" % (type(e).__name__, e)))
                     cnt["stall_s"] += time.perf_counter() - t0
-                    yield idx, kind, host, lens
+                    if not keep:
+                        continue
+                    if len(keep) < len(idx):          # (rare) drop the failed rows: the batch shrinks, the others go on
+                        host = host[keep].contiguous()
+                        if self._pin_memory():
+                            host = host.pin_memory()
+                        idx = [idx[r] for r in keep]
+                    if kind == "samples" and min(real) != max(real):
+                        # equal-length bucket (several 30 s segments, plugin vocoder) with a truncated member: one batch per row
+                        for r in range(len(idx)):
+                            yield idx[r:r + 1], kind, host[r:r + 1, :real[r]], real[r:r + 1]
+                        continue
+                    yield idx, kind, host, real
 
-            writes = []
-            for idx, out_host, lens_out in self.restore_batches(decoded(), your_vocoder_func, streams, mode):
-                ov = out_host.numpy()       # (the views keep the pinned block alive until its rows are encoded)
-                for r, i in enumerate(idx):
-                    writes.append(pool.submit(encode_from, ov[r:r + 1, :lens_out[r]], i))
-                    written.append(names[i])
-            for w in writes:
-                w.result()
+            writes = deque()           # per batch: the futures of its rows (their views keep the batch's pinned result alive)
+            dev_failed = []
+
+            def drain(limit):
+                while len(writes) > limit:
+                    for i, w in writes.popleft():
+                        try:
+                            w.result()
+                            written.append(names[i])
+                            done.append(i)
+                        except Exception as e:    # noqa: BLE001 -- a full disk / unwritable name costs this file
+                            failed.append((i, "%s: %s" % (type(e).__name__, e)))
+
+            for idx, out_host, lens_out in self._restore_batches_isolated(decoded(), dev_failed, your_vocoder_func, streams, mode):
+                ov = out_host.numpy()
+                writes.append([(i, pool.submit(encode_from, ov[r:r + 1, :lens_out[r]], i)) for r, i in enumerate(idx)])
+                drain(ahead + 2)       # bounded backlog: pinned results do not pile up behind a slow disk
+            drain(0)
+            failed.extend(dev_failed)
         if stats is not None:
-            stats.update(rank=rank, world=world, files=len(mine), folder_files=len(files), batches=len(plan),
-                         audio_s=sum(lengths[i] for i in mine) / 44100.0, wall_s=time.perf_counter() - t_start,
+            stats.update(rank=rank, world=world, files=len(written), folder_files=len(files), batches=len(plan),
+                         audio_s=sum(real_len[i] for i in done) / 44100.0, wall_s=time.perf_counter() - t_start,
                          decode_worker_s=cnt["decode_s"], encode_worker_s=cnt["encode_s"],
-                         device_waited_for_decode_s=cnt["stall_s"], io_threads=max(1, io_threads))
+                         device_waited_for_decode_s=cnt["stall_s"], io_threads=io_threads,
+                         failed=sorted((files[i], why) for i, why in failed), skipped=sorted(skipped),
+                         truncated=sorted((files[i], n, m) for i, n, m in truncated))
         return sorted(written)
 
     @staticmethod

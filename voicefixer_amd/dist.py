@@ -57,6 +57,51 @@ def gather_counters(values, device=None, group=None):
     return [x.tolist() for x in allt]
 
 
+def gather_objects(obj, group=None):
+    """All ranks' picklable ``obj`` as a list, on every rank (the folder job's failure / skip lists: names and reasons
+    are not numbers).  World size 1 / no group: ``[obj]``."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return [obj]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, obj, group=group)
+    return out
+
+
+def default_io_threads(world=1, cores=None):
+    """Decode / encode workers per rank of a folder job: the host's cores / (2 * ranks on this node), between 2 and 8 --
+    eight ranks x eight workers (the single-rank default) would fight over a 64-core host while the workers of one
+    rank need about 0.3 worker-seconds per 2560 s of audio (profiles/r04_folder_256x10s.json)."""
+    import os
+    if cores is None:
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 8
+    return max(2, min(8, cores // (2 * max(1, int(world)))))
+
+
+def pin_rank_cpus(local_rank, local_world):
+    """Give rank ``local_rank`` of ``local_world`` on this node its own contiguous slice of the cores this process may
+    run on (sched_setaffinity), so the ranks' interpreter threads and I/O workers do not migrate across each other's
+    caches.  Returns the slice (list of core ids), or None when there is nothing to split (one rank, fewer cores than
+    ranks, no affinity API)."""
+    import os
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        return None
+    local_world = int(local_world)
+    if local_world <= 1 or len(cores) < 2 * local_world:
+        return None
+    lo, hi = shard_range(len(cores), int(local_rank), local_world)
+    mine = cores[lo:hi]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    return mine
+
+
 def free_port():
     import socket
     with socket.socket() as sk:
