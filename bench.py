@@ -133,7 +133,7 @@ def cpu_baseline(args, w1, gpu_out):
     return out
 
 
-def host_to_host_leg(pipe, args, n, dev):
+def host_to_host_leg(pipe, args, n, dev, compute_streams=None):
     """SURVEY.md 8(d) / BASELINE.md 4.6: host-resident float32 waveforms -> host-resident float32 waveforms.
     Pinned buffers, a different batch every step, H2D / compute / D2H on three streams with event hand-offs
     (input and output double buffered), all inside the timed region."""
@@ -143,6 +143,8 @@ def host_to_host_leg(pipe, args, n, dev):
     dev_in = [torch.empty((B, n), device=dev) for _ in range(2)]
     s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
+    cs = [st for st in (compute_streams or []) if st is not None] or [main]   # compute alternates over these (the folder job's two)
+    pipe.set_streams(len(cs))
     ev_in = [torch.cuda.Event() for _ in range(2)]     # H2D of slot k finished
     ev_free = [torch.cuda.Event() for _ in range(2)]   # compute has consumed dev_in[k]
     ev_done = [torch.cuda.Event() for _ in range(2)]   # D2H of slot k finished
@@ -156,11 +158,13 @@ def host_to_host_leg(pipe, args, n, dev):
                     s_in.wait_event(ev_free[k])
                 dev_in[k].copy_(host_in[k], non_blocking=True)
                 ev_in[k].record(s_in)
-            main.wait_event(ev_in[k])
-            y = pipe.restore(dev_in[k], n)
-            ev_free[k].record(main)
+            c = cs[i % len(cs)]
+            c.wait_event(ev_in[k])
+            with torch.cuda.stream(c):
+                y = pipe.restore(dev_in[k], n)
+            ev_free[k].record(c)
             ev_y = torch.cuda.Event()
-            ev_y.record(main)
+            ev_y.record(c)
             with torch.cuda.stream(s_out):
                 s_out.wait_event(ev_y)
                 if i >= 2:
@@ -177,7 +181,7 @@ def host_to_host_leg(pipe, args, n, dev):
     pipe.check()
     assert torch.isfinite(host_out[0]).all() and torch.isfinite(host_out[1]).all()
     return {"value": round(B * args.seconds * steps / dt, 2), "unit": "x real-time",
-            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "compute_streams": len(cs),
             "pcie_bytes_per_step": 2 * B * n * 4,
             "note": "pinned host waveform -> pinned host waveform, H2D/D2H double buffered on copy streams inside the "
                     "timed region, a different batch per step (SURVEY.md 8(d)); file decode/encode excluded"}
@@ -296,25 +300,34 @@ def folder_job(args, rank, world, dev, dist, dry=False):
         pipe = vf._get_pipe()
     barrier()      # (rank 0 has written the folders)
     ext = (".wav", ".flac") if args.folder else (".wav",)
-    vf.restore_folder(warm_in, warm_out, batch_size=args.batch, io_threads=args.io_threads, rank=rank, world=world, extensions=ext)
+    vf.restore_folder(warm_in, warm_out, batch_size=args.batch, io_threads=args.io_threads or None, rank=rank, world=world, extensions=ext)
     barrier()
     st = {}
     t0 = time.perf_counter()
-    vf.restore_folder(ind, outd, batch_size=args.batch, io_threads=args.io_threads, rank=rank, world=world, stats=st,
+    vf.restore_folder(ind, outd, batch_size=args.batch, io_threads=args.io_threads or None, rank=rank, world=world, stats=st,
                       streams=args.folder_streams, extensions=ext)
     barrier()
     dt = time.perf_counter() - t0
-    # the HBM-resident rate of the same build in the same process (one stream, no per-launch events): bench.py's headline loop
+    # the HBM-resident rate of the same build in the same process (bench.py's headline loop: consecutive batches alternating over
+    # the same number of streams as the folder job's device stage, no per-launch events)
     hbm_ms = float("nan")
     if not dry:
         x = synth_batch(args.batch, n, 1000 + rank, dev)
-        pipe.restore(x, n)
+        pool = vf._streams(args.folder_streams)
+        pipe.set_streams(len(pool))
+        for st_ in pool:
+            st_.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(st_):
+                pipe.restore(x, n)
         torch.cuda.synchronize()
+        nrep = max(2 * len(pool), args.steps)
         t1 = time.perf_counter()
-        for _ in range(max(2, args.steps)):
-            pipe.restore(x, n)
+        for i in range(nrep):
+            with torch.cuda.stream(pool[i % len(pool)]):
+                pipe.restore(x, n)
         torch.cuda.synchronize()
-        hbm_ms = (time.perf_counter() - t1) / max(2, args.steps) * 1e3
+        hbm_ms = (time.perf_counter() - t1) / nrep * 1e3
+        pipe.set_streams(1)
         pipe.check()
     keys = ["files", "audio_s", "wall_s", "decode_worker_s", "encode_worker_s", "device_waited_for_decode_s", "batches"]
     allr = vdist.gather_counters([st[k] for k in keys] + [dt, 0.0 if dry else hbm_ms, float(dev.index) if dev is not None else -1.0],
@@ -338,7 +351,7 @@ def folder_job(args, rank, world, dev, dist, dry=False):
             "config": {"workload": "batched folder restore, disk to disk (BASELINE configs[%d]): %d files of %.0f s, %d per GPU, "
                                    "ragged batches of %d, VoiceFixer.restore_folder mode 0, seeded random weights"
                                    % (3 if world > 1 else 2, int(sum(x[0] for x in allr)), args.seconds, int(allr[0][0]), args.batch),
-                       "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "io_threads": args.io_threads,
+                       "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "io_threads": st.get("io_threads", args.io_threads),
                        "streams": args.folder_streams, "host_cores": os.cpu_count(), "folder": base if synthetic else args.folder,
                        "parallelism": "files dealt to %d rank(s) by dist.deal_files (no data-path collective; one all-gather of counters)" % world},
             "hbm_resident": None if dry else {"value": round(hbm_value, 2), "ms_per_step": round(max(x[8] for x in allr), 3)},
@@ -435,8 +448,11 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="issue consecutive steps (batches) round-robin on this many HIP streams")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="issue consecutive steps (one batch each) round-robin on this many HIP streams: 2 = the product "
+                         "configuration (VoiceFixer.restore_batch / restore_folder: one batch's low-occupancy phases -- GRU "
+                         "recurrence, deep UNet levels -- overlap the next batch's convolutions); the single-stream figure "
+                         "and the per-kernel roofline (clean, un-overlapped launch durations) come from a second leg")
     ap.add_argument("--no-events", action="store_true",
                     help="development: time the steps without the per-launch HIP events (no roofline object)")
     ap.add_argument("--no-bf16x3", action="store_true",
@@ -455,7 +471,8 @@ def main():
                     help="BASELINE configs[2]/[3] disk to disk: FILES_PER_GPU x N synthetic --seconds utterances as PCM16 WAV on "
                          "tmpfs through VoiceFixer.restore_folder (ranks share the folder, dist.deal_files deals the files)")
     ap.add_argument("--folder", type=str, default="", help="the same job on an existing folder of .wav / .flac files")
-    ap.add_argument("--io-threads", type=int, default=8, help="decode / encode workers per rank of the folder job")
+    ap.add_argument("--io-threads", type=int, default=0,
+                    help="decode / encode workers per rank of the folder job (0 = dist.default_io_threads: host cores / (2 * ranks), 2..8)")
     ap.add_argument("--folder-streams", type=int, default=2, help="HIP streams of the folder job's device stage")
     ap.add_argument("--dry-run", action="store_true",
                     help="test hook: rehearse the N-rank launch on CPU (gloo, no device work)")
@@ -506,22 +523,32 @@ def main():
             torch.cuda.synchronize()
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    if args.graph:
+        streams = streams[:1]     # (graph replay is a single-stream feature: Pipeline.restore bypasses it otherwise)
 
-    def run_steps(k):
+    def run_steps(k, pool=None):
+        pool = streams if pool is None else pool
+        pipe.set_streams(len(pool))   # (sizes the two-CU GRU launches so that every stream's launch can become resident)
         last = None
         for i in range(k):
-            if len(streams) == 1:
+            if len(pool) == 1 and pool[0] is None:
                 last = pipe.restore(ring[i % NRING], n)
             else:  # consecutive batches on alternating streams: one batch's GRU overlaps the other's convolutions
-                with torch.cuda.stream(streams[i % len(streams)]):
+                with torch.cuda.stream(pool[i % len(pool)]):
                     last = pipe.restore(ring[i % NRING], n)
+        if len(pool) > 1:             # the caller's stream joins every side stream (what restore_batches' drain does)
+            for st in pool:
+                torch.cuda.current_stream(dev).wait_stream(st)
         return last
 
+    SINGLE = [None]                   # the single-stream leg: torch's current stream
+    if len(streams) == 1:
+        streams = SINGLE
     out = run_steps(args.warmup)
     barrier()
     if not args.no_events:
         # pre-created timing events (creating one costs ~10 us of host time: visible in a launch-bound batch-1 run)
-        ops.EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(800 * max(args.steps, 1))]
+        ops.EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(800 * max(args.steps, 1) * (2 if len(streams) > 1 else 1))]
         for e in ops.EVENT_POOL[:8]:
             e.record()  # first use of an event allocates its backing object
         torch.cuda.synchronize()
@@ -531,13 +558,30 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     prof, ops.PROFILE = ops.PROFILE, None
-    ops.EVENT_POOL = None
     if prof is None:
+        ops.EVENT_POOL = None
         if rank == 0:
-            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "events": False}), flush=True)
+            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "events": False, "streams": len(streams)}), flush=True)
         return
     assert torch.isfinite(out).all()
     pipe.check()  # device-side error flags (two-CU GRU hand-off)
+    # ---- second leg (only when the timed region ran on several streams): the same K steps on ONE stream.  Its wall time is
+    # `single_stream`; its per-launch HIP events are what the roofline is computed from -- in the multi-stream timed region the
+    # kernels of two batches share the chip, so an event bracket there also contains the other stream's work (reported beside
+    # it as roofline.timed_region, not hidden)
+    prof_timed, dt_single = None, None
+    if len(streams) > 1:
+        run_steps(1, SINGLE)
+        barrier()
+        prof_timed, ops.PROFILE = prof, []
+        t1 = time.perf_counter()
+        run_steps(args.steps, SINGLE)
+        barrier()
+        dt_single = time.perf_counter() - t1
+        prof, ops.PROFILE = ops.PROFILE, None
+        pipe.check()
+        pipe.set_streams(len(streams))
+    ops.EVENT_POOL = None
     last_idx = (args.steps - 1) % NRING  # ``out`` is the restoration of ring[last_idx]
 
     per_rank = [{"rank": 0, "device": "cuda:%d" % dev.index, "wall_s": round(dt, 4)}]
@@ -603,19 +647,23 @@ def main():
             return 0.5         # both halves Winograd F(4,3)
         return 1.0
 
-    by_fam = {}
-    stft_bytes, stft_secs, stft_n = 0, 0.0, 0
-    for tile, macs, e0, e1 in prof:
-        if tile == -1:  # the STFT->mel front-end: `macs` carries its algorithmic bytes
-            stft_bytes += macs
-            stft_secs += e0.elapsed_time(e1) * 1e-3
-            stft_n += 1
-            continue
-        key, name, rx = family(tile)
-        d = by_fam.setdefault(key, [0, 0, 0.0, name, rx, exec_factor(key)])
-        d[0] += 1
-        d[1] += macs
-        d[2] += e0.elapsed_time(e1) * 1e-3
+    def by_family(events):
+        fams, sb, ss, sn = {}, 0, 0.0, 0
+        for tile, macs, e0, e1 in events:
+            if tile == -1:  # the STFT->mel front-end: `macs` carries its algorithmic bytes
+                sb += macs
+                ss += e0.elapsed_time(e1) * 1e-3
+                sn += 1
+                continue
+            key, name, rx = family(tile)
+            d = fams.setdefault(key, [0, 0, 0.0, name, rx, exec_factor(key)])
+            d[0] += 1
+            d[1] += macs
+            d[2] += e0.elapsed_time(e1) * 1e-3
+        return fams, sb, ss, sn
+
+    by_fam, stft_bytes, stft_secs, stft_n = by_family(prof)
+    dt_roof = dt if dt_single is None else dt_single      # the wall time of the leg the events belong to
     conv_time = sum(d[2] for d in by_fam.values())
     conv_macs = sum(d[1] * d[5] for d in by_fam.values())
     conv_macs_direct = sum(d[1] for d in by_fam.values())
@@ -655,12 +703,22 @@ def main():
         "algorithmic_gflop_per_launch": round(2.0 * macs * xf / launches / 1e9, 3),
         "all_conv_kernels": {"achieved": round(2.0 * conv_macs / conv_time / 1e12, 2),
                              "direct_equivalent": round(2.0 * conv_macs_direct / conv_time / 1e12, 2),
-                             "time_share_of_step": round(conv_time / dt, 4) if world == 1 else None},
+                             "time_share_of_step": round(conv_time / dt_roof, 4) if world == 1 else None},
         "families": {d[3]: {"launches_per_step": d[0] // args.steps, "ms_per_step": round(d[2] / args.steps * 1e3, 2),
                             "tflops": round(2.0 * d[1] * d[5] / d[2] / 1e12, 1),
                             **({"direct_equivalent_tflops": round(2.0 * d[1] / d[2] / 1e12, 1)} if d[5] != 1.0 else {})}
                      for d in sorted(by_fam.values(), key=lambda d: -d[2])[:8]},
     }
+    if prof_timed is not None:
+        fam2 = by_family(prof_timed)[0]
+        dom = next((d for d in fam2.values() if d[4] == krx), None)
+        roofline["measured_on"] = ("the single-stream leg (K steps on one stream right after the timed region): un-overlapped launch "
+                                   "durations.  roofline.timed_region = the same family's event brackets inside the %d-stream timed "
+                                   "region, where a bracket also contains whatever the other stream ran meanwhile" % len(streams))
+        if dom is not None:
+            roofline["timed_region"] = {"streams": len(streams), "avg_launch_ms": round(dom[2] / dom[0] * 1e3, 4),
+                                        "achieved": round(2.0 * dom[1] * dom[5] / dom[2] / 1e12, 2),
+                                        "frac": round(2.0 * dom[1] * dom[5] / dom[2] / 1e12 / peak, 4)}
     if xf != 1.0:
         roofline["algorithm"] = ("Winograd F(4,3) along the dilated axis: 6 fp32 MFMA products per 4 outputs instead of 12; "
                                  "achieved / frac / algorithmic_gflop_per_launch count the EXECUTED products"
@@ -699,15 +757,18 @@ def main():
         "value_definition": ("whole-job audio seconds per wall second with the inputs resident in HBM when the timed region "
                              "starts and the outputs left there (the bench contract); value_host_to_host = the same from "
                              "pinned host waveforms to pinned host waveforms, H2D / D2H inside the timed region (SURVEY.md 8(d))"),
-        "config": {"workload": "batched folder restore (BASELINE configs[2]): one batch of %d x %.0f s 44.1 kHz "
-                               "utterances per step, VoiceFixer.restore mode 0, seeded random weights"
-                               % (args.batch, args.seconds),
+        "config": {"workload": ("batched folder restore (BASELINE configs[2]): one batch of %d x %.0f s 44.1 kHz "
+                                "utterances per step, VoiceFixer.restore mode 0, seeded random weights"
+                                % (args.batch, args.seconds)) if args.batch > 1 else
+                               ("VoiceFixer.restore mode 0, single %.0f s 44.1 kHz mono utterance per step (BASELINE configs[1]%s), "
+                                "seeded random weights" % (args.seconds, "" if abs(args.seconds - 10.0) < 1e-9 else " at another length")),
                    "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "frames": 1 + n // 441,
                    "arithmetic": ("fp32 operands, fp32 MFMA accumulation everywhere; k=3 / 3x3 convolutions evaluated as Winograd "
                                   "F(4,3) (the C=64 stage: one fused launch per layer with both halves F(4,3) for dilations <= 27, two F(4,3) launches for the wider ones): half "
                                   "of the direct sum's products, rounding ~3x the direct sum's (DESIGN.md 3.0b; VFX_WINO=0 runs the direct sums)") if args.math == "f32"
                                  else "opt-in split-bf16 products (three bf16 MFMAs per fp32 product), fp32 accumulation",
                    "parallelism": "utterance sharding x%d (no data-path collective)" % world},
+        "streams": len(streams),
         "path_tflops": round(2.0 * path_macs(n) * args.batch * world * args.steps / dt / 1e12, 2),
         "requested_gpus": requested, "visible_devices": torch.cuda.device_count(),
         "rccl": {"backend": dist.get_backend() if dist is not None else None, "world_size": world},
@@ -715,6 +776,17 @@ def main():
         "lib_build_id": build_id,
         "roofline": roofline,
     }
+    if dt_single is not None:
+        dts = dt_single
+        if dist is not None:
+            t = torch.tensor([dt_single], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t.item())
+        line["single_stream"] = {"value": round(audio_seconds / dts, 2), "unit": "x real-time",
+                                 "ms_per_step": round(dts / args.steps * 1e3, 3), "steps": args.steps,
+                                 "two_streams_over_single": round(dts / dt, 4),
+                                 "note": "the same K steps issued on one stream (what `value` was before round 5); the roofline's "
+                                         "launch durations are this leg's"}
     if requested != world:
         line["note_gpus"] = ("--gpus %d was requested, %d rank(s) ran (visible HIP devices: %d)"
                              % (requested, world, torch.cuda.device_count()))
@@ -737,7 +809,7 @@ def main():
             "note": "opt-in VoiceFixer.set_math('bf16x3'); parity bound 1e-3 RMS"}
 
     if world == 1 and not args.no_host_leg:
-        line["host_to_host"] = host_to_host_leg(pipe, args, n, dev)
+        line["host_to_host"] = host_to_host_leg(pipe, args, n, dev, streams)
         # SURVEY.md 8(d)'s host-waveform -> host-waveform figure, at the top level next to `value` (which the bench
         # contract defines with inputs resident in HBM)
         line["value_host_to_host"] = line["host_to_host"]["value"]
