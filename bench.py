@@ -765,7 +765,7 @@ def main():
                    "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "frames": 1 + n // 441,
                    "arithmetic": ("fp32 operands, fp32 MFMA accumulation everywhere; k=3 / 3x3 convolutions evaluated as Winograd "
                                   "F(4,3) (the C=64 stage: one fused launch per layer with both halves F(4,3) for dilations <= 27, two F(4,3) launches for the wider ones): half "
-                                  "of the direct sum's products, rounding ~3x the direct sum's (DESIGN.md 3.0b; VFX_WINO=0 runs the direct sums)") if args.math == "f32"
+                                  "of the direct sum's products, rounding ~3x the direct sum's (DESIGN.md 3.0b; engine.set_winograd(False) / --selfcheck run the direct sums)") if args.math == "f32"
                                  else "opt-in split-bf16 products (three bf16 MFMAs per fp32 product), fp32 accumulation",
                    "parallelism": "utterance sharding x%d (no data-path collective)" % world},
         "streams": len(streams),

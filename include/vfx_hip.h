@@ -123,10 +123,10 @@ uint64_t vfx_launch_count(void);
  *   code 16           conv_x3_kernel<BM,BL,...>                  (opt-in bf16x3 arithmetic)
  *   code 51 / 52 / 54 convw_kernel<BM,BL,*,*,NT=2|3,*,false>     (1-D, activation chunks of 8 / 16 / 32 channels)
  *   code 59           convw_kernel<BM,BL,*,*,NT=9,*,false>       (3x3 on a pitch map)
- *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32, chunks of 8 / 16 / 32 channels)
- *   code 71 / 72 / 74 convw_kernel<BM,BL,*,*,3,*,2>              (vfx_resblock2_f32: second half as Winograd F(2,3))
- *   code 91 / 92 / 94 convw_kernel<BM,BL,*,*,3,*,3>              (vfx_resblock3_f32: second half as Winograd F(4,3))
- *   code 96           resblk4_kernel                             (vfx_resblock4_f32: both halves as Winograd F(4,3))
+ *   code 61 / 62 / 64 convw_kernel<BM,BL,*,*,3,*,true>           (vfx_resblock_f32: direct sums, chunks of 8 / 16 / 32 channels)
+ *   code 71 / 72 / 74 convw_kernel<BM,BL,*,*,3,*,2>              (vfx_resblock_f32 with w2_wino: second half as Winograd F(2,3))
+ *   code 91 / 92 / 94 convw_kernel<BM,BL,*,*,3,*,3>              (vfx_resblock_f32 with w2_wino4: second half as Winograd F(4,3))
+ *   code 96           resblk4_kernel                             (vfx_resblock_f32 with w1_wino4 + w2_wino4: both halves F(4,3))
  *   code 80           convwg4_kernel<..>                          (Winograd F(4,3), 1-D), BL = output positions
  *   code 88           convwg4s_kernel<..>                         (Winograd F(4,3), 3x3 on a pitch map, kernel columns share one tile) */
 int vfx_last_conv_tile(void);
@@ -147,37 +147,32 @@ int vfx_conv1d_f32(const vfx_tensor* x, const float* w_packed, const float* bias
 
 /* One whole ResStack layer, fused (voicefixer/vocoder/model/modules.py:592-609, one iteration of the loop):
  *   y[b,n,l] = post( x[b,n,l] + bias2[n] + conv_k3_d1( lrelu_s( bias1 + conv_k3_dil( lrelu_s(x) ) ) )[b,n,l] )
- * for C = 64 or 128 channels.  The intermediate tensor lives in LDS (one tile of BL columns per workgroup, BL-2
- * outputs), never in HBM.  x needs a guard band >= dilation + BL + 8 (vfx_tensor.guard); y must NOT alias x (a tile
- * reads the input columns of its neighbours).  Weights in the w_direct layout of vfx_act.  post_act as vfx_act.post_act. */
-int vfx_resblock_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
-                     const float* w2_direct, const float* bias2, int B, int C, int L, int dilation, float slope,
-                     int post_act, float post_slope, vfx_stream_t stream);
-/* The same with the SECOND convolution's weights also given as their Winograd F(2,3) transform (w2_wino, may be NULL:
- * U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2, four slabs packed like w_direct, packing.py::pack_wino): the
- * dilation-1 half of the layer then forms 4 products per output pair instead of 6 on the LDS tile (C = 64 with the
- * 256-column tile, C = 128).  Results differ from vfx_resblock_f32 by fp32 rounding only. */
-int vfx_resblock2_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
-                      const float* w2_direct, const float* bias2, const float* w2_wino, int B, int C, int L,
-                      int dilation, float slope, int post_act, float post_slope, vfx_stream_t stream);
-/* The same, with the second convolution's weights also offered as their Winograd F(4,3) transform (w2_wino4, may be NULL:
- * six slabs U = G w as for vfx_act.w_wino4, packing.py::pack_wino4).  C = 64 with 16-byte aligned rows of x and y: the
- * dilation-1 half forms 6 products per output QUAD instead of 12 (63 quads per 256-column tile; residual and stores move
- * as 16-byte vectors).  Anything else falls back to w2_wino / the direct weights as vfx_resblock2_f32 does. */
-int vfx_resblock3_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
-                      const float* w2_direct, const float* bias2, const float* w2_wino, const float* w2_wino4,
-                      int B, int C, int L, int dilation, float slope, int post_act, float post_slope,
-                      vfx_stream_t stream);
-
-/* The same, with the FIRST (dilated) convolution's weights also offered as their Winograd F(4,3) transform (w1_wino4, may be NULL).
- * C = 64 with both transforms, 16-byte aligned rows and a dilation whose blocks of 4 d positions fill a 256-column tile (d <= 32
- * with >= 48 of 64 quad columns used: the stage's d = 1, 3, 9, 27): BOTH halves of the layer form 6 products per four outputs
- * (resblk4_kernel: the dilated half along the dilated axis, its output transform into the LDS tile; x needs no guard band there).
- * Anything else is vfx_resblock3_f32.  Results differ from vfx_resblock_f32 by fp32 rounding only. */
-int vfx_resblock4_f32(const vfx_tensor* x, const vfx_tensor* y, const float* w1_direct, const float* bias1,
-                      const float* w2_direct, const float* bias2, const float* w2_wino, const float* w2_wino4,
-                      const float* w1_wino4, int B, int C, int L, int dilation, float slope, int post_act, float post_slope,
-                      vfx_stream_t stream);
+ * for C = 64 or 128 channels.  The intermediate tensor lives in LDS (one tile of columns per workgroup), never in HBM.
+ * x needs a guard band >= dilation + 264 (vfx_tensor.guard) unless resblk4_kernel takes the launch; y must NOT alias x
+ * (a tile reads the input columns of its neighbours).  post_act as vfx_act.post_act.
+ * Weights: both convolutions in the w_direct layout of vfx_act (required), and optionally their Winograd transforms --
+ * the library picks the cheapest arithmetic the operands allow, results differ by fp32 rounding only:
+ *   w2_wino   F(2,3) of the SECOND convolution (U0 = w0, U1 = (w0+w1+w2)/2, U2 = (w0-w1+w2)/2, U3 = w2, four slabs packed like
+ *             w_direct, packing.py::pack_wino): its dilation-1 half forms 4 products per output pair instead of 6 on the LDS
+ *             tile (C = 64 with the 256-column tile, C = 128);
+ *   w2_wino4  F(4,3) of the second convolution (six slabs U = G w as vfx_act.w_wino4, packing.py::pack_wino4), C = 64 with
+ *             16-byte aligned rows of x and y: 6 products per output QUAD instead of 12 (63 quads per 256-column tile; residual
+ *             and stores move as 16-byte vectors);
+ *   w1_wino4  F(4,3) of the FIRST (dilated) convolution, C = 64 together with w2_wino4 and a dilation whose blocks of 4 d
+ *             positions fill a 256-column tile (d <= 32 with >= 48 of 64 quad columns used: the stage's d = 1, 3, 9, 27): BOTH
+ *             halves form 6 products per four outputs (resblk4_kernel: the dilated half along the dilated axis, its output
+ *             transform into the LDS tile; x needs no guard band there). */
+typedef struct {
+    const float* w1_direct;  /* required */
+    const float* bias1;      /* may be NULL */
+    const float* w2_direct;  /* required */
+    const float* bias2;      /* may be NULL */
+    const float* w2_wino;    /* optional */
+    const float* w2_wino4;   /* optional */
+    const float* w1_wino4;   /* optional */
+} vfx_resblock_w;
+int vfx_resblock_f32(const vfx_tensor* x, const vfx_tensor* y, const vfx_resblock_w* w, int B, int C, int L,
+                     int dilation, float slope, int post_act, float post_slope, vfx_stream_t stream);
 
 /* ConvTranspose1d(Cin, Cout, kernel 2s, stride s, padding s/2 + s%2, output_padding s%2):
  * Lin -> s*Lin.  Polyphase: s phases x 2 taps.  w_packed = [2s][CinPad][Cout], slab k is

@@ -29,6 +29,30 @@ def test_header_symbols_exported():
     assert h.vfx_version() >= 100
 
 
+def test_release_library_exports_the_c_abi_only_and_reads_no_environment():
+    """The dynamic symbol table of libvfx_hip.so is exactly the set of functions include/vfx_hip.h declares (csrc/vfx.map: no
+    C++-mangled helper leaks out), and the release build holds none of the development switches: the VFX_* environment names that
+    select kernels (VFX_DEV_ENV, csrc/vfx_common.h) are compiled in by `make dev` only."""
+    import subprocess
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    rel = os.path.join(ROOT, "voicefixer_amd", "libvfx_hip.so")      # (not VFX_LIB: the release library is what ships)
+    hdr = open(os.path.join(ROOT, "include", "vfx_hip.h")).read()
+    names = set(re.findall(r"\b(vfx_[a-z0-9_]+)\s*\(", hdr)) - {"vfx_tensor", "vfx_act", "vfx_resblock_w"}
+    out = subprocess.run(["nm", "-D", "--defined-only", rel], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split()}
+    assert exported == names, (sorted(exported - names), sorted(names - exported))
+    blob = open(rel, "rb").read()
+    switches = set(re.findall(rb"VFX_[A-Z0-9_]{3,}", blob))
+    assert not switches, sorted(switches)
+    # ... and the sources read the environment through VFX_DEV_ENV only
+    csrc = os.path.join(ROOT, "voicefixer_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".inc")):
+            assert "getenv(" not in open(os.path.join(csrc, f)).read(), f
+
+
 def test_missing_checkpoints_raise_like_reference(tmp_path, monkeypatch):
     monkeypatch.setenv("HOME", str(tmp_path))
     with pytest.raises(RuntimeError, match="Error 0"):
@@ -217,7 +241,7 @@ def _unpack_direct(wd):
 
 
 def test_pack_wino_is_the_f23_weight_transform():
-    """packing.pack_wino (vfx_resblock2_f32: w2_wino): with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the inputs
+    """packing.pack_wino (vfx_resblock_f32: w2_wino): with V = (d0-d2, d1+d2, d2-d1, d1-d3) of the inputs
     x[q-d], x[q], x[q+d], x[q+2d] and m_k = U_k V_k, the pair (m0+m1+m2, m1-m2-m3) must be the direct k = 3 convolution
     at q and q + d -- evaluated here in float64 on the CPU from the PACKED weights."""
     import torch.nn.functional as F

@@ -457,7 +457,7 @@ def test_resblock_fused(case):
         ops.resblock(xd, xd, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil)      # in place is refused
     with pytest.raises(_lib.VfxError):
         ops.resblock(xd[:, :32], yd[:, :32], w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil)   # C = 32 is not covered
-    # the same layer with its dilation-1 half as Winograd F(2,3) on the LDS tile (vfx_resblock2_f32, w2_wino)
+    # the same layer with its dilation-1 half as Winograd F(2,3) on the LDS tile (vfx_resblock_f32 with w2_wino)
     yd2 = ops.guarded(B, Cn, L, 2187 + 264, DEV)
     yd2._vfx_base.fill_(float("nan"))
     ops.resblock(xd, yd2, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2,
@@ -470,7 +470,7 @@ def test_resblock_fused(case):
     if Cn != 64:
         return
     # ... and as Winograd F(4,3): wave = 32 channels x 32 output quads, residual and stores as 16-byte vectors, the quad
-    # that straddles the end of a row of odd length as single elements (vfx_resblock3_f32, w2_wino4)
+    # that straddles the end of a row of odd length as single elements (vfx_resblock_f32 with w2_wino4)
     yd3 = ops.guarded(B, Cn, L, 2187 + 264, DEV)
     yd3._vfx_base.fill_(float("nan"))
     ops.resblock(xd, yd3, w1d, b1.to(DEV), w2d, b2.to(DEV), L, dil, 0.01, post, 0.2,
@@ -481,7 +481,7 @@ def test_resblock_fused(case):
     _close(yd3[:, :, :L], ref, 2e-5)
     base = yd3._vfx_base
     assert torch.isnan(base[:, :, :g]).all() and torch.isnan(base[:, :, g + L:]).all()
-    # ... and with the FIRST (dilated) convolution as F(4,3) too (vfx_resblock4_f32, w1_wino4: resblk4_kernel) for the dilations whose
+    # ... and with the FIRST (dilated) convolution as F(4,3) too (vfx_resblock_f32 with w1_wino4: resblk4_kernel) for the dilations whose
     # blocks of 4d positions fit the 256-column tile (1, 3, 9, 27); wider dilations keep the form above
     yd4 = ops.guarded(B, Cn, L, 2187 + 264, DEV)
     yd4._vfx_base.fill_(float("nan"))

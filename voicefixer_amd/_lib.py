@@ -28,6 +28,11 @@ class vfx_act(C.Structure):
                 ("math", C.c_int), ("w_x3", C.c_void_p), ("w_direct", C.c_void_p), ("w_wino4", C.c_void_p)]
 
 
+class vfx_resblock_w(C.Structure):
+    _fields_ = [("w1_direct", C.c_void_p), ("bias1", C.c_void_p), ("w2_direct", C.c_void_p), ("bias2", C.c_void_p),
+                ("w2_wino", C.c_void_p), ("w2_wino4", C.c_void_p), ("w1_wino4", C.c_void_p)]
+
+
 PRE_NONE, PRE_LRELU, PRE_AFFINE_LRELU = 0, 1, 2
 POST_NONE, POST_LRELU, POST_ELU, POST_TANH, POST_SIGMOID, POST_LRELU_SNAKE = 0, 1, 2, 3, 4, 5
 PAD_ZERO, PAD_REFLECT = 0, 1
@@ -45,10 +50,7 @@ SIGNATURES = {
     "vfx_launch_count": (C.c_uint64, []),
     "vfx_last_conv_tile": (_I, []),
     "vfx_conv1d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _I, _A, _P]),
-    "vfx_resblock_f32": (_I, [_T, _T, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
-    "vfx_resblock2_f32": (_I, [_T, _T, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
-    "vfx_resblock3_f32": (_I, [_T, _T, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
-    "vfx_resblock4_f32": (_I, [_T, _T, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
+    "vfx_resblock_f32": (_I, [_T, _T, C.POINTER(vfx_resblock_w), _I, _I, _I, _I, C.c_float, _I, C.c_float, _P]),
     "vfx_convtr1d_f32": (_I, [_T, _P, _P, _T, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_conv2d_f32": (_I, [_T, _P, _P, _T, _T, _I, _I, _I, _I, _I, _I, _A, _P]),
     "vfx_convtr2d_3x3s2_f32": (_I, [_T, _P, _T, _I, _I, _I, _I, _I, _A, _P]),

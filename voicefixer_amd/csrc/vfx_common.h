@@ -5,7 +5,7 @@
 #include <atomic>
 #include "../../include/vfx_hip.h"
 
-extern std::atomic<uint64_t> g_vfx_launches;
+extern __attribute__((visibility("hidden"))) std::atomic<uint64_t> g_vfx_launches;
 
 #define VFX_LAUNCHED() (g_vfx_launches.fetch_add(1, std::memory_order_relaxed))
 
@@ -15,7 +15,18 @@ static inline int vfx_last_error() {
 }
 
 // Zero ``bytes`` (a multiple of 4) of device memory on a stream with a KERNEL (vfx_misc.hip), not hipMemsetAsync: see there.
-int vfx_zero_u32(void* p, size_t bytes, hipStream_t s);
+// (internal: hidden visibility, not part of the C ABI)
+__attribute__((visibility("hidden"))) int vfx_zero_u32(void* p, size_t bytes, hipStream_t s);
+
+// Development switches (VFX_WINO4_D1, VFX_KC16, ...): environment variables that change WHICH kernel a launch runs.  They are read
+// only by -DVFX_DEV builds (`make dev` -> libvfx_hip_dev.so, selected with VFX_LIB=...); the release library reads no
+// environment variable at all, and the switch names do not appear in it (tests/test_api_cpu.py greps the .so).
+#ifdef VFX_DEV
+#include <stdlib.h>
+#define VFX_DEV_ENV(name) getenv(name)
+#else
+#define VFX_DEV_ENV(name) (static_cast<const char*>(nullptr))
+#endif
 
 static inline bool vfx_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

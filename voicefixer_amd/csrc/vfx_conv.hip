@@ -58,6 +58,22 @@ extern "C" int vfx_debug_read_x(unsigned long long* out, int reset) {
     if (reset) { unsigned long long z[6] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_dbgx), z, sizeof(z)); }
     return 0;
 }
+// per-workgroup timeline of convwg4_kernel: wave 0 of every workgroup appends {HW_ID | XCC_ID << 32, linear workgroup id, s_memtime at
+// entry / K loop start / K loop end / exit} to a device buffer the tool hands in (tools/wg4_timeline.py)
+__device__ unsigned long long* g_trace_buf;
+__device__ unsigned int g_trace_cap, g_trace_n;
+extern "C" int vfx_debug_trace(unsigned long long* buf, unsigned int cap_records) {
+    const unsigned int z = 0;
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace_buf), &buf, sizeof(buf));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace_cap), &cap_records, sizeof(cap_records));
+    hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), &z, sizeof(z));
+    return 0;
+}
+extern "C" unsigned int vfx_debug_trace_count(void) {
+    unsigned int n = 0;
+    hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_trace_n), sizeof(n));
+    return n;
+}
 #define DBG_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
 #else
 #define DBG_T(v)
@@ -1042,7 +1058,7 @@ static const ConvTables* device_tables(const ConvTables& tb) {
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     {
-        static const bool dump = getenv("VFX_DEBUG_ARGS") && atoi(getenv("VFX_DEBUG_ARGS")) != 0;  // development
+        static const bool dump = VFX_DEV_ENV("VFX_DEBUG_ARGS") && atoi(VFX_DEV_ENV("VFX_DEBUG_ARGS")) != 0;  // development
         if (dump) {
             fprintf(stderr, "conv table:");
             const unsigned* w = reinterpret_cast<const unsigned*>(&tb);
@@ -1075,7 +1091,7 @@ static int launch_one(const ConvArgs& a, dim3 grid, size_t lds, hipStream_t s) {
         attr_set |= 1ull << (attr_dev & 63);
     }
     {
-        static const bool dump = getenv("VFX_DEBUG_ARGS") && atoi(getenv("VFX_DEBUG_ARGS")) != 0;  // development
+        static const bool dump = VFX_DEV_ENV("VFX_DEBUG_ARGS") && atoi(VFX_DEV_ENV("VFX_DEBUG_ARGS")) != 0;  // development
         if (dump) {
             fprintf(stderr, "conv_taps<%d,%d,%d,%d,%d,%d,%d,%d> grid %u %u %u lds %zu args:", BM, BL, WGM, WGL, KC, (int)FAST,
                     NXV, (int)SPLITK, grid.x, grid.y, grid.z, lds);
@@ -1262,7 +1278,7 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
         phs = &row_spec;
     }
     int wrow_slabs = 3;  // slabs per "row" step
-    static const bool tapsplit_all = getenv("VFX_X3_TAPSPLIT") && atoi(getenv("VFX_X3_TAPSPLIT")) != 0;  // development
+    static const bool tapsplit_all = VFX_DEV_ENV("VFX_X3_TAPSPLIT") && atoi(VFX_DEV_ENV("VFX_X3_TAPSPLIT")) != 0;  // development
     if (rows == 1 && nphase == 1 && phs[0].ntaps == 3 && phs[0].taps[0].slab == 0 && phs[0].taps[1].slab == 1 &&
         phs[0].taps[2].slab == 2 && phs[0].taps[1].off == 0 && phs[0].taps[0].off == -phs[0].taps[2].off &&
         (phs[0].taps[2].off > 60 || (tapsplit_all && phs[0].taps[2].off > 0))) {
@@ -1297,7 +1313,7 @@ static int try_launch_x3(ConvArgs a, const vfx_tensor* x, int nphase, const Phas
     int BM, BL;
     if (Cout % 128 == 0) { BM = 128; BL = 128; }
     else if (Cout % 64 == 0) {
-        static const bool bl128 = getenv("VFX_X3_BL128") && atoi(getenv("VFX_X3_BL128")) != 0;  // development
+        static const bool bl128 = VFX_DEV_ENV("VFX_X3_BL128") && atoi(VFX_DEV_ENV("VFX_X3_BL128")) != 0;  // development
         if (!seg && Lq >= 4096 && !bl128) { BM = 64; BL = 256; }
         else { BM = 64; BL = 128; }
     } else {
@@ -1452,11 +1468,11 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     // K-chunk depth: 8 channels per chunk unless the staged tiles would need more than 4 float4 per
     // thread (activations) / the weight tile more than its slot budget -> 4 channels per chunk
     // development switch: VFX_WAVES8=1 runs the two big tiles with 8 waves (wave tile 32x64)
-    static const bool waves8_env = getenv("VFX_WAVES8") && atoi(getenv("VFX_WAVES8")) != 0;
+    static const bool waves8_env = VFX_DEV_ENV("VFX_WAVES8") && atoi(VFX_DEV_ENV("VFX_WAVES8")) != 0;
     const bool waves8 = waves8_env && ((tc.BM == 128 && tc.BL == 128) || (tc.BM == 64 && tc.BL == 256));
     const int nthr = waves8 ? 512 : 256;
     // development switch: VFX_KC16=1 lets 3-tap (or fewer) launches on the 128x128 tile use 16-channel chunks
-    static const bool kc16_env = getenv("VFX_KC16") && atoi(getenv("VFX_KC16")) != 0;
+    static const bool kc16_env = VFX_DEV_ENV("VFX_KC16") && atoi(VFX_DEV_ENV("VFX_KC16")) != 0;
     // Exact-width halo tiles: when the taps of every phase span only a few positions (dilation <= 3, transposed
     // convolutions, k = 1) the halo is staged INSIDE the BL columns and a tile produces BL - span outputs.  The
     // activation tile then needs exactly one staging slot per thread (half the loads, conversions and LDS writes
@@ -1475,7 +1491,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         maxspan = mx - mn > maxspan ? mx - mn : maxspan;
         all_segments &= !((long long)tc.BL + (mx - mn) + 3 <= (long long)phs[p].ntaps * (tc.BL + 3));
     }
-    static const int exact_off = getenv("VFX_NO_EXACT") ? atoi(getenv("VFX_NO_EXACT")) : 0;  // development: 1 all, 2 segments
+    static const int exact_off = VFX_DEV_ENV("VFX_NO_EXACT") ? atoi(VFX_DEV_ENV("VFX_NO_EXACT")) : 0;  // development: 1 all, 2 segments
     bool exact = exact_off != 1 && x->guard > 0 && pad_mode != VFX_PAD_REFLECT && in_mask == 0 && !waves8 &&
                  ((maxspan > 0 && maxspan <= 8) || (all_segments && exact_off != 2));
     ConvTables tb;
@@ -1500,7 +1516,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
         lds = (2ull * (a.xs_floats + a.ws_floats) + 2ull * a.CinPad) * sizeof(float);
         {
             // development knob: VFX_LDS_MIN_KB pads the request to limit workgroups per CU (occupancy studies)
-            static const long pad_kb = getenv("VFX_LDS_MIN_KB") ? atol(getenv("VFX_LDS_MIN_KB")) : 0;
+            static const long pad_kb = VFX_DEV_ENV("VFX_LDS_MIN_KB") ? atol(VFX_DEV_ENV("VFX_LDS_MIN_KB")) : 0;
             if (pad_kb > 0 && lds < (size_t)pad_kb * 1024) lds = (size_t)pad_kb * 1024;
         }
         if (lds > 160 * 1024) return VFX_ERANGE;
@@ -1541,7 +1557,7 @@ static int launch_conv(const vfx_tensor* x, const float* w, const float* bias, c
     // serial K-chunks) is cut along K so that the whole chip works on it; plain output maps only
     a.ksplit = 1;
     {
-        static const bool splitk_off = getenv("VFX_NO_SPLITK") && atoi(getenv("VFX_NO_SPLITK")) != 0;  // development
+        static const bool splitk_off = VFX_DEV_ENV("VFX_NO_SPLITK") && atoi(VFX_DEV_ENV("VFX_NO_SPLITK")) != 0;  // development
         const int nchunks = (Cin + KC - 1) / KC;
         const long long nwg = (long long)ntiles * (nphase * Cout / tc.BM) * B;
         const bool plain_map = nphase == 1 && q_shift == 31 && o_rs == 0 && o_cs == 1 && phs[0].ooff == 0 && Lq <= Lout;

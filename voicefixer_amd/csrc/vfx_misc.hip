@@ -135,7 +135,7 @@ extern "C" int vfx_conv1d_cout1_f32(const vfx_tensor* x, const float* w, const f
     dim3 grid((L + 255) / 256, B);
     const int mask = out_mask_log2 > 0 ? (1 << out_mask_log2) - 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    static const bool x4_off = getenv("VFX_COUT1_X4") && atoi(getenv("VFX_COUT1_X4")) == 0;   // development
+    static const bool x4_off = VFX_DEV_ENV("VFX_COUT1_X4") && atoi(VFX_DEV_ENV("VFX_COUT1_X4")) == 0;   // development
     const bool vec_ok = !x4_off && mask == 0 && ((x->cstride | x->bstride | y->bstride) & 3) == 0 &&
                         (((uintptr_t)x->ptr | (uintptr_t)y->ptr) & 15) == 0;
     if (k == 7 && vec_ok)

@@ -145,7 +145,7 @@ def conv1d(x, w, bias, y, L, k, dilation=1, pad_mode=PAD_ZERO, act=None, res=Non
 
 
 def resblock(x, y, w1d, b1, w2d, b2, L, dilation, slope=0.01, post=POST_NONE, post_slope=0.0, w2g=None, w2g4=None, w1g4=None):
-    """One fused ResStack layer (vfx_resblock4_f32): x (B,C,>=L) guarded view -> y (B,C,>=L), y must not alias x.
+    """One fused ResStack layer (vfx_resblock_f32): x (B,C,>=L) guarded view -> y (B,C,>=L), y must not alias x.
     ``w2g`` (packing.pack_wino of the second convolution, optional): its dilation-1 half runs as Winograd F(2,3);
     ``w2g4`` (packing.pack_wino4, optional, C = 64): as F(4,3) when the rows of x and y are 16-byte aligned;
     ``w1g4`` (packing.pack_wino4 of the FIRST convolution, optional, C = 64): with w2g4 and a dilation <= 27 BOTH halves run as
@@ -154,9 +154,10 @@ def resblock(x, y, w1d, b1, w2d, b2, L, dilation, slope=0.01, post=POST_NONE, po
     B, Cn = x.shape[0], x.shape[1]
     xd, yd = tdesc(x), tdesc(y)
     e0 = _prof_begin()
-    rc = _lib.lib().vfx_resblock4_f32(C.byref(xd), C.byref(yd), _ptr(w1d), _ptr(b1), _ptr(w2d), _ptr(b2), _ptr(w2g),
-                                      _ptr(w2g4), _ptr(w1g4), B, Cn, L, dilation, float(slope), post, float(post_slope), _stream())
-    check(rc, "vfx_resblock4_f32")
+    wts = _lib.vfx_resblock_w(_ptr(w1d), _ptr(b1), _ptr(w2d), _ptr(b2), _ptr(w2g), _ptr(w2g4), _ptr(w1g4))
+    rc = _lib.lib().vfx_resblock_f32(C.byref(xd), C.byref(yd), C.byref(wts), B, Cn, L, dilation, float(slope), post,
+                                     float(post_slope), _stream())
+    check(rc, "vfx_resblock_f32")
     _prof_end(e0, 2 * B * L * Cn * Cn * 3)
 
 

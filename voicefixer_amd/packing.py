@@ -55,7 +55,7 @@ def pack_direct(w_packed):
 def pack_wino(w_packed):
     """[3][CinPad][Cout] (tap slabs of a k = 3 Conv1d) -> [4][CinPad/8][Cout][8]: the Winograd F(2,3) weight
     transform U0 = w0, U1 = (w0 + w1 + w2)/2, U2 = (w0 - w1 + w2)/2, U3 = w2 (sums in float64, rounded once) in the
-    A-operand layout of pack_direct: the second half of the fused ResStack layer (vfx_resblock2_f32: w2_wino)."""
+    A-operand layout of pack_direct: the second half of the fused ResStack layer (vfx_resblock_f32: w2_wino)."""
     assert w_packed.shape[0] == 3
     g = w_packed.double()
     u = torch.stack([g[0], (g[0] + g[1] + g[2]) * 0.5, (g[0] - g[1] + g[2]) * 0.5, g[2]])

@@ -102,7 +102,7 @@ def main(argv=None):
     bad, _ = report(res, args.tol)
     if bad:
         print("selfcheck FAILED: %s" % ", ".join("%s/%s %.2e" % b for b in bad))
-        print("(VFX_WINO=0 in the environment runs every convolution as the direct sum)")
+        print("(voicefixer_amd.engine.set_winograd(False) runs every convolution as the direct sum)")
         return 1
     print("selfcheck ok: every stage within %.0e of the direct fp32 sums" % args.tol)
     return 0
