@@ -596,7 +596,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 96: resblk4_kernel (fused layer, both halves F(4,3)), 16: conv_x3_kernel,
-    # 80: convwg4_kernel (Winograd F(4,3), 1-D), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74 | 91/92/94: fused layer with a Winograd F(2,3) | F(4,3) second half,
+    # 80 / 81: convwg4_kernel / convwg4p_kernel (Winograd F(4,3), 1-D; one tile per workgroup / persistent), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74 | 91/92/94: fused layer with a Winograd F(2,3) | F(4,3) second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
     import re
@@ -624,10 +624,10 @@ def main():
             wgm = bm // 32
             return ("wino4", bm, bl, 3, "s"), "convwg4s_kernel<%d,%d,*> (3x3 as Winograd F(4,3) along the map rows, kernel columns share one staged tile)" % (
                 wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+[,>]" % (wgm, 4 // wgm)
-        if code == 80:
+        if code in (80, 81):   # 81: convwg4p_kernel, the persistent form of the same tile (one family: the same arithmetic on the same tile)
             wgm = bm // 32
-            return ("wino4", bm, bl), "convwg4_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; D1 = the dilation-1 instance)" % (
-                wgm, 4 // wgm, bm, bl // 4), r"convwg4_kernel<%d, %d, (true|false)[,>]" % (wgm, 4 // wgm)
+            return ("wino4", bm, bl), "convwg4[p]_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; p = persistent workgroups, pipeline across tiles)" % (
+                wgm, 4 // wgm, bm, bl // 4), r"convwg4p?_kernel<%d, %d, (true|false)[,>]" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \

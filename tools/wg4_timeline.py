@@ -38,6 +38,8 @@ def analyse(rec, name, ms):
     life = np.median(t3 - t0)
     kfrac = np.median((t2 - t1) / np.maximum(t3 - t0, 1))
     tot_pe = hid_pe = 0.0
+    span_sum = res_sum = 0.0                       # per CU: first entry .. last exit, and the sum of the workgroups' resident times
+    gaps = []                                      # exit of a workgroup -> entry of the next one that takes a free slot of the CU
     occ = np.zeros(5)
     offs = []
     ncu = 0
@@ -49,6 +51,13 @@ def analyse(rec, name, ms):
         a0, a1, a2, a3 = t0[m], t1[m], t2[m], t3[m]
         o = np.argsort(a0)
         a0, a1, a2, a3 = a0[o], a1[o], a2[o], a3[o]
+        span_sum += float(a3.max() - a0.min())
+        res_sum += float((a3 - a0).sum())
+        # slot hand-over: every entry after the first residency round takes the slot of the earliest not yet re-used exit
+        ends = np.sort(a3)
+        nslot = int(((a0 < a3.min())).sum())      # workgroups resident before the first exit = slots of this CU
+        for i in range(nslot, len(a0)):
+            gaps.append(float(a0[i] - ends[i - nslot]))
         # event sweep: +1 at K-loop start, -1 at K-loop end -> time with n workgroups in their K loop
         ev = np.concatenate([np.stack([a1, np.ones_like(a1)], 1), np.stack([a2, -np.ones_like(a2)], 1)])
         ev = ev[np.argsort(ev[:, 0], kind="stable")]
@@ -60,7 +69,6 @@ def analyse(rec, name, ms):
         for i in range(len(a0)):
             for (s, e) in ((a0[i], a1[i]), (a2[i], a3[i])):
                 tot_pe += e - s
-                cover = np.zeros(0)
                 lo_ = np.maximum(a1, s)
                 hi_ = np.minimum(a2, e)
                 ov = np.clip(hi_ - lo_, 0, None)
@@ -74,6 +82,11 @@ def analyse(rec, name, ms):
     occ = occ / max(occ.sum(), 1)
     h, _ = np.histogram(np.array(offs), bins=10, range=(0, 1))
     h = h / max(h.sum(), 1)
+    g = np.array(gaps) if gaps else np.zeros(1)
+    tick_ghz = span_sum / max(ncu, 1) / (ms * 1e6)
+    print("%-10s slots per CU %.2f busy (sum of residencies / span / slots); ticks per ns %.3f; exit -> next entry on the freed slot: median %.0f, "
+          "mean %.0f, 90th pct %.0f ticks (%.2f us median)" % (name, res_sum / max(span_sum, 1), tick_ghz, np.median(g), g.mean(), np.percentile(g, 90),
+                                                             np.median(g) / max(tick_ghz, 1e-9) / 1e3))
     print("%-10s %.3f ms  records %d on %d CUs  lifetime %.0f ticks, K loop %.0f %% of it | CU time with n workgroups in their K loop: "
           "0: %.1f %%  1: %.1f %%  2: %.1f %%  3+: %.1f %% | prologue+epilogue time under a co-resident K loop: %.0f %% | "
           "start offsets of co-resident workgroups (tenths of a lifetime): %s | wave slots seen: %s"
@@ -108,15 +121,17 @@ def main():
         for _ in range(2):
             ops.conv1d(x, wpc, bias, y, L, k, dil, 0, act, res=res, wd=wd, wg4=wg4)
         torch.cuda.synchronize()
+        buf.zero_()
+        torch.cuda.synchronize()
         h.vfx_debug_trace(C.c_void_p(buf.data_ptr()), cap)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         ops.conv1d(x, wpc, bias, y, L, k, dil, 0, act, res=res, wd=wd, wg4=wg4)
         e1.record()
         torch.cuda.synchronize()
-        n = min(int(h.vfx_debug_trace_count()), cap)
         h.vfx_debug_trace(None, 0)
-        rec = buf[:n].cpu().numpy().astype(np.uint64)
+        rec = buf.cpu().numpy().astype(np.uint64)
+        rec = rec[rec[:, 1] != 0]                   # (records are indexed by the linear workgroup id; column 1 = id + 1)
         analyse(rec, name + ("(stack)" if stack else ""), e0.elapsed_time(e1))
 
 
