@@ -331,7 +331,7 @@ def folder_job(args, rank, world, dev, dist, dry=False):
         pipe.check()
     keys = ["files", "audio_s", "wall_s", "decode_worker_s", "encode_worker_s", "device_waited_for_decode_s", "batches"]
     allr = vdist.gather_counters([st[k] for k in keys] + [dt, 0.0 if dry else hbm_ms, float(dev.index) if dev is not None else -1.0],
-                                 dev if (dist is not None and not dry) else None)
+                                 dev if (dist is not None and not dry and dist.is_initialized() and dist.get_backend() == "nccl") else None)
     if rank == 0:
         outs = sorted(os.listdir(outd))
         assert len(outs) == int(sum(x[0] for x in allr)) == st["folder_files"], (len(outs), st["folder_files"])
@@ -401,7 +401,14 @@ def self_launch(args, argv):
     scales is voicefixer/__main__.py:187-212 (the launcher runs unchanged on 1..8 visible devices)."""
     visible = args.gpus if args.dry_run else torch.cuda.device_count()
     nproc = max(1, min(args.gpus, visible))
-    if nproc < args.gpus:
+    if args.oversubscribe and not args.dry_run and visible >= 1:
+        # rehearsal of the N-rank job on FEWER devices (a one-GPU box): all N launcher ranks run, rank r on device r % visible, the
+        # counters travel over gloo (RCCL refuses two ranks on one device).  What it shows: the launch, the deal, per-rank I/O pools
+        # and CPU slices, every file written once -- not a scaling number (the ranks share the device).
+        nproc = args.gpus
+        os.environ["VFX_BENCH_OVERSUBSCRIBE"] = "1"
+        print("bench.py: --oversubscribe: %d ranks on %d visible device(s), gloo for the counters" % (nproc, visible), file=sys.stderr, flush=True)
+    elif nproc < args.gpus:
         print("bench.py: WARNING: --gpus %d requested but only %d HIP device(s) visible -> running %d rank(s); "
               "n_gpus in the JSON line is the number of ranks that ran" % (args.gpus, visible, nproc),
               file=sys.stderr, flush=True)
@@ -474,6 +481,9 @@ def main():
     ap.add_argument("--io-threads", type=int, default=0,
                     help="decode / encode workers per rank of the folder job (0 = dist.default_io_threads: host cores / (2 * ranks), 2..8)")
     ap.add_argument("--folder-streams", type=int, default=2, help="HIP streams of the folder job's device stage")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="with --gpus N on a box with fewer devices: run all N ranks anyway (rank r on device r %% visible, gloo for the "
+                         "counters) -- a rehearsal of the N-rank folder job, not a scaling measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="test hook: rehearse the N-rank launch on CPU (gloo, no device work)")
     args = ap.parse_args()
@@ -499,7 +509,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if os.environ.get("VFX_BENCH_OVERSUBSCRIBE") == "1" and world > torch.cuda.device_count():
+            dist.init_process_group(backend="gloo")   # (--oversubscribe: several ranks share a device, which RCCL refuses)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     if args.synth_folder or args.folder:
         return folder_job(args, rank, world, dev, dist)
