@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (no 2:1 sparsity), same guide
 SR = 44100
-TRAFFIC_PROFILE = "r04_pmc_hbm_traffic_bench_b32.json"  # tools/profile_round.sh -> tools/pmc_summary.py
+TRAFFIC_PROFILE = "r05_pmc_hbm_traffic_bench_b32.json"  # tools/profile_round.sh -> tools/pmc_summary.py
 
 
 def synth_batch(batch, n, seed, device):
@@ -683,7 +683,7 @@ def main():
     launches, macs, secs, kname, krx, xf = max(by_fam.values(), key=lambda d: d[2])
     achieved = 2.0 * macs * xf / secs / 1e12
     # HBM bytes per launch of that family: PMC counters cannot be read live; they come from the committed rocprofv3
-    # --pmc passes over this same command (tools/profile_round.sh -> profiles/r03_pmc_hbm_traffic_bench_b32.json)
+    # --pmc passes over this same command (tools/profile_round.sh -> profiles/<TRAFFIC_PROFILE>)
     # -- and only when that summary was taken with THIS library: the summary carries vfx_build_id() of the build it
     # profiled; a kernel change without a re-profile reports traffic = null and says why
     traffic, traffic_note = None, None

@@ -323,6 +323,46 @@ def test_mode1_matches_oracle(vf):
     assert _rms(out, ref) < 1e-4
 
 
+def test_folder_job_survives_bad_files_on_the_device(vf, tmp_path):
+    """Round-4 review item 2 on the REAL device stage (tests/test_dist_cpu.py runs the same folder on two gloo ranks with a stub):
+    a header cut off before its data chunk, a 500-sample file, a file whose decoder raises and a file shorter than its header
+    says sit between good files -- every good file is written, the short-data one at its real length and equal to restoring
+    those samples alone, the three bad ones are listed with a reason, nothing half-written is left, and a second run with
+    skip_existing touches nothing."""
+    import importlib.util
+    import warnings
+    from scipy.io import wavfile
+    spec = importlib.util.spec_from_file_location("tdc", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_dist_cpu.py"))
+    tdc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tdc)
+    ind, outd, single = str(tmp_path / "in"), str(tmp_path / "out"), tmp_path / "single"
+    single.mkdir()
+    lens = tdc._make_ragged_folder(ind, 7, seed=11)
+    bad, trunc = tdc._add_bad_files(ind)
+    good = dict(lens, **trunc)
+    st = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")          # (scipy warns about the truncated data chunk)
+        names = vf.restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st)
+        assert sorted(names) == sorted(good) == sorted(os.listdir(outd))        # (no .part-* leftovers either)
+        assert sorted(n for n, _ in st["failed"]) == sorted(bad) and all(why for _, why in st["failed"])
+        assert st["truncated"] == [("truncated.wav", 4000, 2900)]
+        for name, n in good.items():
+            sr, y = wavfile.read(os.path.join(outd, name))
+            assert sr == 44100 and y.shape == (n,) and y.dtype == np.int16, name
+        x = audio_io.load_wav(os.path.join(ind, "truncated.wav"))
+        assert x.shape == (2900,)
+        audio_io.save_wave(vf.restore_inmem(x, cuda=True), str(single / "t.wav"))
+        a = wavfile.read(os.path.join(outd, "truncated.wav"))[1].astype(np.int32)
+        b = wavfile.read(str(single / "t.wav"))[1].astype(np.int32)
+        assert np.max(np.abs(a - b)) <= 1
+        before = {f: os.path.getmtime(os.path.join(outd, f)) for f in os.listdir(outd)}
+        st2 = {}
+        assert vf.restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st2, skip_existing=True) == []
+        assert sorted(st2["skipped"]) == sorted(good) and sorted(n for n, _ in st2["failed"]) == sorted(bad)
+        assert before == {f: os.path.getmtime(os.path.join(outd, f)) for f in os.listdir(outd)}
+
+
 def test_restore_folder_matches_per_file_restore(vf, tmp_path):
     """Folder driver (voicefixer/__main__.py:176-212 semantics): every *.wav of the input folder appears
     under the same name in the output folder and equals what restore() writes for that file alone
@@ -473,6 +513,33 @@ def test_restore_batch_ragged_rows(vf):
     assert _rms(outs[2], ref) < 2e-5
     with pytest.raises(_lib.VfxError):
         vf._get_pipe().restore_rows(torch.zeros((2, 441 * 40), device="cuda"), [441 * 36, 1000])   # < 1025 samples
+
+
+def test_ragged_batches_never_read_uninitialised_memory(vf, monkeypatch):
+    """Round-4 review: the mode-1 ragged path builds its cut rows in a torch.empty buffer, and the staging / workspace tensors of the
+    whole path are torch.empty too -- correct only if no kernel ever reads past a row's own end (vectorised tail loads included).
+    With EVERY floating-point torch.empty of the process returning NaN-filled memory -- pinned staging rows, the cut buffer, every
+    activation buffer and workspace of the engine -- ragged batches of mode 0 and mode 1 must come back bit-identical."""
+    g = torch.Generator().manual_seed(77)
+    lens = [441 * 36 + 3, 441 * 36 + 221, 441 * 44 + 17, 441 * 47, 441 * 40 + 1]
+    wavs = [(0.1 * torch.randn(n, generator=g)).numpy() for n in lens]
+    want0 = vf.restore_batch(wavs, batch_size=8, streams=1)
+    want1 = vf.restore_batch(wavs, batch_size=8, streams=1, mode=1)
+    real_empty = torch.empty
+
+    def nan_empty(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_floating_point() and t.numel():
+            t.fill_(float("nan"))
+        return t
+
+    monkeypatch.setattr(torch, "empty", nan_empty)
+    got0 = vf.restore_batch(wavs, batch_size=8, streams=1)
+    got1 = vf.restore_batch(wavs, batch_size=8, streams=1, mode=1)
+    monkeypatch.undo()
+    for w, a, b in zip(want0 + want1, got0 + got1, lens + lens):
+        assert np.isfinite(a).all()
+        assert np.array_equal(w, a)
 
 
 def test_ragged_rows_cross_unet_and_tile_boundaries(vf):

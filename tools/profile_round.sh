@@ -8,7 +8,10 @@ TAG=${1:-rXX}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $PWD/bench.py --batch 32 --no-cpu-baseline --no-bf16x3 --no-host-leg $*"
+# --streams 1: one batch at a time, so that a kernel's duration in the trace is ITS duration (with the default two streams the
+# launches of two batches overlap and every duration contains whatever the other stream ran meanwhile); bench.py's roofline takes
+# its launch durations from a single-stream leg for the same reason, and the two must agree
+BENCH="python $PWD/bench.py --batch 32 --streams 1 --no-cpu-baseline --no-bf16x3 --no-host-leg $*"
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o r -- $BENCH --steps 3 --warmup 1 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc -o fetch -- $BENCH --steps 1 --warmup 1 > /dev/null 2> $OUT/fetch.log

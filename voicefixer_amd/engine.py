@@ -221,11 +221,20 @@ class VocoderEngine:
             ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
-            unfused_from = None
+            # The fused C = 64 stage runs its WIDELY dilated layers (d > 27: a block of 4 d positions does not fit the fused tile) as two
+            # Winograd F(4,3) launches each, in place on xs, from the first such layer on.  Decided once per stage: the index must be
+            # even (the fused ping-pong has the data back in xs there, and everything after it runs in place), and the launch must be
+            # large enough for convwg4_kernel to take it (it declines fewer than 512 tiles: B * Lo / 256) -- a short single utterance
+            # keeps the fused layer instead of falling to two non-Winograd launches.
+            first_unfused = None
+            if (fused and _UNFUSE_WIDE and c == 64 and _ARITH["winograd"] and all(l[7] is not None and l[8] is not None for l in layers)
+                    and B * Lo >= 1 << 18):
+                wide = [i for i in range(len(layers) - 1) if 3 ** i > 27 and i % 2 == 0]
+                first_unfused = wide[0] if wide else None
+                assert first_unfused is None or first_unfused % 2 == 0
             for i, (w1, w1d, b1, w2, w2d, b2, w2g, w1g4, w2g4) in enumerate(layers):
                 last = i == len(layers) - 1
-                if fused and not (_UNFUSE_WIDE and c == 64 and 3 ** i > 27 and i % 2 == 0 and w1g4 is not None and _ARITH["winograd"]
-                                  and i + 1 < len(layers)) and not (unfused_from is not None and i >= unfused_from):
+                if fused and (first_unfused is None or i < first_unfused):
                     # one launch per layer, intermediate tile in LDS; input and output ping-pong between xs and ys
                     # (a tile reads its neighbours' input columns, so the update cannot be in place)
                     post, pslope = POST_NONE, 0.0
@@ -235,8 +244,6 @@ class VocoderEngine:
                     ops.resblock(src, dst, w1d, b1, w2d, b2, Lo, 3 ** i, 0.01, post, pslope, w2g=_wg(w2g), w2g4=_wg(w2g4),
                                  w1g4=_wg(w1g4))
                     continue
-                if fused and unfused_from is None:
-                    unfused_from = i      # from the first widely dilated layer on: two F(4,3) launches per layer, in place on xs
                 if not wino and not fused:
                     w1g4 = w2g4 = None
                 ops.conv1d(xs, w1, b1, ys, Lo, 3, 3 ** i, PAD_ZERO, self.act_c1, w3=self._x3(w1), wd=w1d, wg4=_wg(w1g4))
