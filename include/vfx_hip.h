@@ -128,6 +128,8 @@ uint64_t vfx_launch_count(void);
  *   code 91 / 92 / 94 convw_kernel<BM,BL,*,*,3,*,3>              (vfx_resblock_f32 with w2_wino4: second half as Winograd F(4,3))
  *   code 96           resblk4_kernel                             (vfx_resblock_f32 with w1_wino4 + w2_wino4: both halves F(4,3))
  *   code 80           convwg4_kernel<..>                          (Winograd F(4,3), 1-D), BL = output positions
+ *   code 81           convwg4p_kernel<..>                         (the same tile on persistent workgroups: the two long launches of a
+ *                     ResStack layer, tap / staging / weight pipeline running across tiles)
  *   code 88           convwg4s_kernel<..>                         (Winograd F(4,3), 3x3 on a pitch map, kernel columns share one tile) */
 int vfx_last_conv_tile(void);
 
