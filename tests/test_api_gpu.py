@@ -938,6 +938,29 @@ def test_cli_folder_under_the_launcher_on_rccl(vf, seeded_states, tmp_path, monk
             assert x1.shape == x2.shape and np.max(np.abs(x1.astype(np.int32) - x2.astype(np.int32))) <= 1
 
 
+def test_bench_oversubscribed_folder_job_two_ranks_on_one_device(tmp_path):
+    """``bench.py --gpus 2 --oversubscribe --synth-folder 4``: both launcher ranks run on this box's one GPU (rank r on device r %
+    visible), the counters travel over gloo, every file of the synthetic folder is written exactly once and the JSON line says what
+    ran -- the rehearsal of the N-rank folder job that profiles/r05_folder_8ranks_on_one_device.json records at N = 8."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe", "--synth-folder", "4", "--batch", "4",
+                        "--folder-streams", "1", "--steps", "2"], cwd=root, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    if torch.cuda.device_count() >= 2:
+        assert j["n_gpus"] == 2
+        return
+    assert j["n_gpus"] == 2 and j["requested_gpus"] == 2 and j["visible_devices"] == 1 and j["rccl"]["backend"] == "gloo"
+    assert [pr["files"] for pr in j["per_rank"]] == [4, 4] and all(pr["device"] == "cuda:0" for pr in j["per_rank"])
+    assert j["value"] > 10 and abs(j["per_rank"][0]["audio_s"] - j["per_rank"][1]["audio_s"]) < 1e-6
+
+
 def test_graph_replays_survive_an_eager_pass_in_between(seeded_states):
     """Round 4 regression: capture, two replays, ONE eager pass of the same shape on the same stream, replays again -- with the peak
     workspace and the GRU mailboxes zeroed by hipMemsetAsync (= memset nodes in the captured graph) every replay after the eager
