@@ -53,6 +53,27 @@ def test_release_library_exports_the_c_abi_only_and_reads_no_environment():
             assert "getenv(" not in open(os.path.join(csrc, f)).read(), f
 
 
+def test_python_package_reads_the_environment_through_the_dev_gate_only(monkeypatch):
+    """voicefixer_amd/*.py consult no VFX_* environment variable unless VFX_DEV=1 (voicefixer_amd/_dev.py, the one gate): the
+    sources touch os.environ only for the launcher's rendezvous variables (RANK / WORLD_SIZE / ..., __main__.py, dist.exec_ranks),
+    and a development switch set WITHOUT the gate changes nothing."""
+    pkg = os.path.join(ROOT, "voicefixer_amd")
+    for f in sorted(os.listdir(pkg)):
+        if not f.endswith(".py") or f == "_dev.py":
+            continue
+        src = open(os.path.join(pkg, f)).read()
+        for m in re.finditer(r"environ[^\n]*", src):
+            assert "VFX_" not in m.group(0), (f, m.group(0))
+        assert "getenv" not in src, f
+    from voicefixer_amd import _dev
+    monkeypatch.delenv("VFX_DEV", raising=False)
+    monkeypatch.setenv("VFX_UNFUSE_WIDE", "0")
+    monkeypatch.setenv("VFX_LIB", "/nonexistent/libvfx_hip.so")
+    assert _dev.dev_env("VFX_UNFUSE_WIDE", "1") == "1" and _dev.dev_env("VFX_LIB", "x") == "x"
+    monkeypatch.setenv("VFX_DEV", "1")
+    assert _dev.dev_env("VFX_UNFUSE_WIDE", "1") == "0"
+
+
 def test_missing_checkpoints_raise_like_reference(tmp_path, monkeypatch):
     monkeypatch.setenv("HOME", str(tmp_path))
     with pytest.raises(RuntimeError, match="Error 0"):

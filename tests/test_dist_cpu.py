@@ -367,3 +367,132 @@ def test_io_thread_default_and_cpu_slices():
     assert vdist.default_io_threads(1, cores=128) == 8 and vdist.default_io_threads(8, cores=128) == 8
     assert vdist.default_io_threads(8, cores=64) == 4 and vdist.default_io_threads(8, cores=8) == 2
     assert vdist.pin_rank_cpus(0, 1) is None
+    # a PINNED rank takes half of its own slice (round 5 divided the slice by the world size again: 32 // 16 = 2 workers)
+    try:
+        vdist._PINNED = list(range(32))
+        assert vdist.default_io_threads(8) == 8
+        vdist._PINNED = list(range(6))
+        assert vdist.default_io_threads(8) == 3
+    finally:
+        vdist._PINNED = None
+
+
+def _pin_worker(q):
+    import torch as t
+    mine = vdist.pin_rank_cpus(1, 2)
+    q.put((mine, sorted(os.sched_getaffinity(0)), t.get_num_threads(), vdist.default_io_threads(2)))
+
+
+def test_pin_rank_cpus_binds_the_slice_and_sizes_the_thread_pools():
+    cores = sorted(os.sched_getaffinity(0))
+    if len(cores) < 4:
+        pytest.skip("needs four cores")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_pin_worker, args=(q,))
+    p.start()
+    mine, aff, nthreads, io = q.get(timeout=120)
+    p.join(60)
+    lo, hi = vdist.shard_range(len(cores), 1, 2)
+    assert mine == aff == cores[lo:hi] and nthreads == len(mine) and io == max(2, min(8, len(mine) // 2))
+
+
+def _scan_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        scanned = [(1000, None), (2000, None), (None, "RuntimeError: not a RIFF/WAVE file: c.wav"), (4000, None)]
+        if rank == 1:
+            scanned[1] = (None, "OSError: [Errno 5] Input/output error")     # a transient read error on ONE rank
+            scanned[3] = (3900, None)                                        # (and a header read while the file was growing)
+        q.put((rank, vdist.agree_on_scan(scanned)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_scan_before_they_deal():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == got[1] == [(1000, None), (None, "rank 1: OSError: [Errno 5] Input/output error"),
+                                (None, "RuntimeError: not a RIFF/WAVE file: c.wav"), (3900, None)]
+    assert vdist.agree_on_scan([(5, None)]) == [(5, None)]       # no process group: unchanged
+
+
+def test_a_failing_batch_source_is_reported_not_dropped(tmp_path):
+    """the iterator that FEEDS the device stage raises at batch 3 of 6 -- the three batches already handed
+    over are yielded, then BatchSourceError is raised (round 5 returned quietly: yielded [0, 1, 2], failed [], exit 0)."""
+    from voicefixer_amd import api
+
+    class Stub(_StubDevice, api.VoiceFixer):
+        pass
+
+    def source():
+        for b in range(6):
+            if b == 3:
+                raise MemoryError("pinned staging for batch 3")
+            yield [b], "ragged", torch.full((1, 8), float(b)), [8]
+
+    failed, seen = [], []
+    with pytest.raises(api.BatchSourceError, match="MemoryError: pinned staging for batch 3"):
+        for tag, out, lens in Stub()._restore_batches_isolated(source(), failed, None, 2, 0):
+            seen.append(tag[0])
+    assert seen == [0, 1, 2] and failed == []
+
+
+def test_folder_job_accounts_for_every_file_when_staging_fails(tmp_path, monkeypatch):
+    """A staging block that cannot be allocated costs the files of THAT batch (listed in stats["failed"]); if the source of
+    batches dies altogether, every file it never reached is listed too -- written + failed + skipped always cover the deal."""
+    from voicefixer_amd import api
+
+    class Stub(_StubDevice, api.VoiceFixer):
+        n_alloc = 0
+
+        @staticmethod
+        def _pin_memory():
+            Stub.n_alloc += 1
+            if Stub.n_alloc == 2:
+                raise MemoryError("cannot pin 2 GB")
+            return False
+
+    ind, outd = str(tmp_path / "in"), str(tmp_path / "out")
+    lens = _make_ragged_folder(ind, 12, seed=5)
+    st = {}
+    names = Stub().restore_folder(ind, outd, batch_size=4, io_threads=2, stats=st)
+    lost = [f for f, why in st["failed"]]
+    assert len(names) == 8 and len(lost) == 4 and sorted(names + lost) == sorted(lens)
+    assert all("staging for a batch of 4 x" in why and "cannot pin 2 GB" in why for _, why in st["failed"])
+
+    class Dies(_StubDevice, api.VoiceFixer):
+        def _restore_batches_isolated(self, items, failed, your_vocoder_func, streams, mode):
+            it = iter(items)
+            first = next(it)
+            yield first[0], -first[2], list(first[3])
+            raise api.BatchSourceError("the batch source failed after OSError: worker pool gone")
+
+    st = {}
+    names = Dies().restore_folder(ind, str(tmp_path / "out2"), batch_size=4, io_threads=2, stats=st)
+    assert len(names) == 4 and len(st["failed"]) == 8 and sorted(names + [f for f, _ in st["failed"]]) == sorted(lens)
+    assert all(why.startswith("not processed: the batch source failed after OSError") for _, why in st["failed"])
+
+
+def test_a_lying_wav_header_cannot_size_the_staging(tmp_path):
+    """The RIFF data chunk promises 400 MB, the file holds 2000 samples: the planning length is what the file can hold."""
+    import numpy as np
+    import struct
+    from scipy.io import wavfile
+    from voicefixer_amd import audio_io
+    p = str(tmp_path / "liar.wav")
+    wavfile.write(p, 44100, np.zeros(2000, np.int16))
+    raw = bytearray(open(p, "rb").read())
+    k = raw.index(b"data")
+    raw[k + 4:k + 8] = struct.pack("<I", 400_000_000)
+    open(p, "wb").write(bytes(raw))
+    assert audio_io.wav_length(p) == 2000

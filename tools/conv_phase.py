@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Per-phase cycle breakdown of conv_taps_kernel (needs a -DVFX_ABL=8 build passed via VFX_LIB)."""
+"""Per-phase cycle breakdown of conv_taps_kernel (needs a -DVFX_ABL=8 build passed via VFX_DEV=1 VFX_LIB)."""
 import ctypes as C, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from voicefixer_amd import ops, packing, _lib

@@ -4,7 +4,7 @@
 With the peak workspace and the GRU mailboxes zeroed by hipMemsetAsync (memset NODES in the captured graph; library builds up to
 3373d8f871350c85) the replays after the eager pass came back divided by ~3 -- the peak rule read a stale workspace -- on every trial;
 with the zeroing as a kernel node (vfx_zero_u32, vfx_misc.hip) all five figures per trial are equal.  Select an older build with
-VFX_LIB=path/to/libvfx_hip.so to see the difference.  The regression test is
+VFX_DEV=1 VFX_LIB=path/to/libvfx_hip.so to see the difference.  The regression test is
 tests/test_api_gpu.py::test_graph_replays_survive_an_eager_pass_in_between."""
 import os
 import sys

@@ -62,8 +62,8 @@ def main():
                 ts.append(time.perf_counter() - t0)
         print("  %d thread(s): resample 48 kHz -> 44.1 kHz %6.0f x real time (%s)"
               % (threads, 4 * threads * secs / min(ts), "vfx_resample_poly_f32" if flac.native() else "scipy upfirdn"), flush=True)
-    if flac.native() and os.environ.get("VFX_FLAC_NATIVE", "1") != "0":
-        env = dict(os.environ, VFX_FLAC_NATIVE="0")
+    if flac.native() and not (os.environ.get("VFX_DEV") == "1" and os.environ.get("VFX_FLAC_NATIVE") == "0"):
+        env = dict(os.environ, VFX_DEV="1", VFX_FLAC_NATIVE="0")
         subprocess.run([sys.executable, os.path.abspath(__file__), str(min(nfiles, 16)), str(secs)], env=env)
 
 

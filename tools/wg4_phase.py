@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Per-phase breakdown of a workgroup's life in convwg4_kernel (development; needs a -DVFX_ABL=8 build passed via VFX_LIB):
-    make -C voicefixer_amd/csrc abl && VFX_LIB=voicefixer_amd/libvfx_hip_abl.so python tools/wg4_phase.py res2_d27 res1_d1 ...
+"""Per-phase breakdown of a workgroup's life in convwg4_kernel (development; needs a -DVFX_ABL=8 build passed via VFX_DEV=1 VFX_LIB):
+    make -C voicefixer_amd/csrc abl && VFX_DEV=1 VFX_LIB=voicefixer_amd/libvfx_hip_abl.so python tools/wg4_phase.py res2_d27 res1_d1 ...
 Wave 0 of every workgroup adds its s_memtime deltas (prologue up to the first barrier, K loop, of which at barriers, epilogue);
 the tool prints the per-workgroup means in microseconds (ticks calibrated by the launch's own wall time) next to the pipe time the
 workgroup's MFMAs need (768 MFMAs x 64 cycles for Cin = 256 ...)."""

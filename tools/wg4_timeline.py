@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-CU timeline of convwg4_kernel workgroups (development; needs the -DVFX_ABL=8 build):
-    make -C voicefixer_amd/csrc abl && VFX_LIB=voicefixer_amd/libvfx_hip_abl.so python tools/wg4_timeline.py res3_d1 res2_d27 ...
+    make -C voicefixer_amd/csrc abl && VFX_DEV=1 VFX_LIB=voicefixer_amd/libvfx_hip_abl.so python tools/wg4_timeline.py res3_d1 res2_d27 ...
 Wave 0 of every workgroup records {HW_ID, XCC_ID, s_memtime at entry / K-loop start / K-loop end / exit}.  The tool groups the
 records by compute unit (XCC, SE, SH, CU from HW_ID) and answers the question the round-4 review asked: are the workgroups that
 share a CU IN PHASE (prologues and epilogues at the same time, nothing hides them) or spread?  Per launch it prints

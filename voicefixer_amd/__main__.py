@@ -179,9 +179,10 @@ def main(argv=None):
         rank = int(os.environ.get("RANK", "0"))
         if torch.cuda.is_available():
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
-        tdist.init_process_group(backend=args.dist_backend)
         from . import dist as vdist
+        # (before the process group: the threads gloo / RCCL create inherit the rank's core slice)
         vdist.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
+        tdist.init_process_group(backend=args.dist_backend)
         if rank != 0:
             args.silent = True        # rank 0 speaks for the job
             process_file = False      # a single file is one rank's work

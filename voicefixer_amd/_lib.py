@@ -8,8 +8,10 @@ import ctypes as C
 import os
 import subprocess
 
+from ._dev import dev_env
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("VFX_LIB", os.path.join(_HERE, "libvfx_hip.so"))  # VFX_LIB: development override
+LIB_PATH = dev_env("VFX_LIB", os.path.join(_HERE, "libvfx_hip.so"))  # VFX_LIB: development override (with VFX_DEV=1 only)
 CSRC = os.path.join(_HERE, "csrc")
 
 

@@ -212,6 +212,12 @@ class _RestorerHandle(nn.Module):
         return {k: (v if v.device == dev else v.to(dev)) for k, v in out.items()}
 
 
+class BatchSourceError(RuntimeError):
+    """The iterator that FEEDS ``_restore_batches_isolated`` raised (staging allocation, decode planning): not a fault of a
+    device batch, so no row-by-row re-issue can recover it -- the batches already issued are finished first, then this
+    is raised; ``restore_folder`` records every file it never got to as failed."""
+
+
 class VoiceFixer(nn.Module):
     """General speech restoration, inference path (voicefixer/base.py)."""
 
@@ -560,9 +566,17 @@ class VoiceFixer(nn.Module):
         from collections import deque
         src = iter(items)
         pending = deque()
+        src_exc = []           # what the batch SOURCE raised (a generator that has raised is finished: nothing more will come)
 
         def feed():
-            for it in src:
+            while not src_exc:
+                try:
+                    it = next(src)
+                except StopIteration:
+                    return
+                except Exception as e:    # noqa: BLE001 -- not a device fault: the batches already issued finish (or are re-issued
+                    src_exc.append(e)     # row by row), then the error goes to the caller, who knows which files it never saw
+                    return
                 pending.append(it)
                 yield it
 
@@ -571,7 +585,11 @@ class VoiceFixer(nn.Module):
                 for tag, out_host, lens_out in self.restore_batches(feed(), your_vocoder_func, streams, mode):
                     pending.popleft()
                     yield tag, out_host, lens_out
+                if src_exc:
+                    raise BatchSourceError("the batch source failed after %s: %s" % (type(src_exc[0]).__name__, src_exc[0])) from src_exc[0]
                 return
+            except BatchSourceError:
+                raise
             except (KeyboardInterrupt, GeneratorExit):
                 raise
             except Exception as exc:    # noqa: BLE001 -- whatever the batch raised costs the rows that raise it again, alone
@@ -653,7 +671,10 @@ class VoiceFixer(nn.Module):
             promises less than a restorable file (0 in a streamed / interrupted recording) is not believed: the file
             is decoded once to see what is really there."""
             try:
-                n = audio_io.wav_length(paths[i], 44100)
+                n, promised = audio_io.wav_length(paths[i], 44100, with_promise=True)
+                if promised != n:         # (a header that promises more than the file holds: planned at what is there)
+                    with lock:
+                        truncated.append((i, promised, n))
                 if n < min_len:
                     n = len(audio_io.load_wav(paths[i], 44100))
                 return n, None
@@ -670,7 +691,7 @@ class VoiceFixer(nn.Module):
             row[m:] = 0.0
             with lock:
                 cnt["decode_s"] += time.perf_counter() - t0
-                if len(x) != n:
+                if len(x) != n and not any(t[0] == i for t in truncated):
                     truncated.append((i, n, len(x)))
             return m
 
@@ -691,7 +712,11 @@ class VoiceFixer(nn.Module):
         written, skipped, done = [], [], []
         with ThreadPoolExecutor(max_workers=io_threads) as pool:
             scanned = list(pool.map(scan, range(len(files))))
-            # every rank sees the same headers, so every rank drops the same files; each dropped file is REPORTED by one rank
+            # every rank must deal from the SAME list: inside an initialised process group of this world size the scans are
+            # all-gathered and a file any rank could not read is dropped by all (dist.agree_on_scan); without a group (explicit
+            # rank / world) the ranks rely on seeing the same headers.  Each dropped file is REPORTED by one rank
+            if world > 1 and vdist.dist.is_available() and vdist.dist.is_initialized() and vdist.dist.get_world_size() == world:
+                scanned = vdist.agree_on_scan(scanned)
             usable = []
             for i, (n, why) in enumerate(scanned):
                 if why is None and n < min_len:
@@ -715,7 +740,12 @@ class VoiceFixer(nn.Module):
                 kind, grp = plan[b]
                 idx = [mine[g] for g in grp]
                 lens = [lengths[i] for i in idx]
-                host = torch.empty((len(idx), max(lens)), dtype=torch.float32, pin_memory=self._pin_memory())
+                try:
+                    host = torch.empty((len(idx), max(lens)), dtype=torch.float32, pin_memory=self._pin_memory())
+                except Exception as e:    # noqa: BLE001 -- a staging block that cannot be had (host memory, pinning) costs THIS batch
+                    for i in idx:
+                        failed.append((i, "staging for a batch of %d x %d samples: %s: %s" % (len(idx), max(lens), type(e).__name__, e)))
+                    return idx, kind, None, lens, []
                 hv = host.numpy()
                 return idx, kind, host, lens, [pool.submit(decode_into, i, hv[r], lens[r]) for r, i in enumerate(idx)]
 
@@ -725,6 +755,8 @@ class VoiceFixer(nn.Module):
                     idx, kind, host, lens, futs = queue.pop(0)
                     if b + ahead < len(plan):
                         queue.append(submit_decode(b + ahead))
+                    if host is None:          # (its staging block could not be allocated: the files are already in `failed`)
+                        continue
                     t0 = time.perf_counter()
                     keep, real = [], []
                     for r, f in enumerate(futs):
@@ -766,19 +798,29 @@ class VoiceFixer(nn.Module):
                         except Exception as e:    # noqa: BLE001 -- a full disk / unwritable name costs this file
                             failed.append((i, "%s: %s" % (type(e).__name__, e)))
 
-            for idx, out_host, lens_out in self._restore_batches_isolated(decoded(), dev_failed, your_vocoder_func, streams, mode):
-                ov = out_host.numpy()
-                writes.append([(i, pool.submit(encode_from, ov[r:r + 1, :lens_out[r]], i)) for r, i in enumerate(idx)])
-                drain(ahead + 2)       # bounded backlog: pinned results do not pile up behind a slow disk
+            source_error = None
+            try:
+                for idx, out_host, lens_out in self._restore_batches_isolated(decoded(), dev_failed, your_vocoder_func, streams, mode):
+                    ov = out_host.numpy()
+                    writes.append([(i, pool.submit(encode_from, ov[r:r + 1, :lens_out[r]], i)) for r, i in enumerate(idx)])
+                    drain(ahead + 2)       # bounded backlog: pinned results do not pile up behind a slow disk
+            except BatchSourceError as e:  # the source died: every batch it had handed over has been finished and is written below
+                source_error = str(e)
             drain(0)
             failed.extend(dev_failed)
+            # the books must balance: every file dealt to this rank is written, failed or skipped -- a file nobody accounted
+            # for (the batch source died before it got there) is reported as failed, never dropped in silence
+            seen = set(done) | {i for i, _ in failed}
+            for i in mine:
+                if i not in seen:
+                    failed.append((i, "not processed: %s" % (source_error or "the device stage ended early")))
         if stats is not None:
             stats.update(rank=rank, world=world, files=len(written), folder_files=len(files), batches=len(plan),
                          audio_s=sum(real_len[i] for i in done) / 44100.0, wall_s=time.perf_counter() - t_start,
                          decode_worker_s=cnt["decode_s"], encode_worker_s=cnt["encode_s"],
                          device_waited_for_decode_s=cnt["stall_s"], io_threads=io_threads,
                          failed=sorted((files[i], why) for i, why in failed), skipped=sorted(skipped),
-                         truncated=sorted((files[i], n, m) for i, n, m in truncated))
+                         truncated=sorted((files[i], n, m) for i, n, m in truncated if i in real_len or i in mine))
         return sorted(written)
 
     @staticmethod

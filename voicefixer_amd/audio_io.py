@@ -49,8 +49,8 @@ def save_wave(frames, fname, sample_rate=SR):
 
 
 def _riff_info(path):
-    """(sample_rate, frames) of a RIFF/WAVE file from its ``fmt `` and ``data`` chunk headers alone -- any bit depth
-    (scipy's memory-mapped read refuses 24-bit PCM, a very common studio format)."""
+    """(sample_rate, frames, frames the header promises) of a RIFF/WAVE file from its ``fmt `` and ``data`` chunk headers alone
+    -- any bit depth (scipy's memory-mapped read refuses 24-bit PCM, a very common studio format)."""
     with open(path, "rb") as f:
         head = f.read(12)
         if len(head) < 12 or head[:4] not in (b"RIFF", b"RF64") or head[8:12] != b"WAVE":
@@ -67,30 +67,37 @@ def _riff_info(path):
             elif cid == b"data":
                 if not block_align:
                     raise RuntimeError("WAV data chunk before the fmt chunk: %s" % path)
-                if size == 0xFFFFFFFF:      # streamed / RF64 file: fall back to what is really there
-                    pos = f.tell()
-                    f.seek(0, 2)
-                    size = f.tell() - pos
-                return int(sr), int(size // block_align)
+                # the header PLANS (staging width of the folder job): never believe more than the file can hold -- a streamed /
+                # RF64 file says 0xFFFFFFFF, a truncated or lying one promises bytes that are not there
+                pos = f.tell()
+                f.seek(0, 2)
+                real = min(size, f.tell() - pos)
+                return int(sr), int(real // block_align), int((real if size == 0xFFFFFFFF else size) // block_align)
             else:
                 f.seek(size + (size & 1), 1)
 
 
-def wav_length(path, sample_rate=SR):
-    """Number of samples ``load_wav(path, sample_rate)`` will return, from the file header alone."""
+def wav_length(path, sample_rate=SR, with_promise=False):
+    """Number of samples ``load_wav(path, sample_rate)`` will return, from the file header (and the file size) alone;
+    ``with_promise``: (that number, the number the header PROMISES) -- they differ for a truncated recording."""
+    promised = None
     if str(path).lower().endswith(".flac"):
         from . import flac
         sr, _, _, n = flac.info(path)
-        if n == 0:      # legal for streamed encoders (unknown length): count what is really there
-            n = flac.read(path)[1].shape[0]
+        # STREAMINFO's total is a promise; a frame holds at most 65535 samples per channel in no fewer than ~8 bytes, which bounds
+        # what a file of this size can decode to (the folder job sizes pinned staging from this number)
+        import os
+        if n == 0 or n > (os.path.getsize(path) // 8 + 1) * 65535:      # 0: legal for streamed encoders (unknown length)
+            n = flac.read(path)[1].shape[0]     # count what is really there
     else:
-        sr, n = _riff_info(path)
-    if sr == sample_rate:
-        return n
-    from math import gcd
-    g = gcd(int(sr), int(sample_rate))
-    up, down = sample_rate // g, sr // g
-    return -(-n * up // down)  # resample_poly: ceil(n * up / down)
+        sr, n, promised = _riff_info(path)
+    promised = n if promised is None else promised
+    if sr != sample_rate:
+        from math import gcd
+        g = gcd(int(sr), int(sample_rate))
+        up, down = sample_rate // g, sr // g
+        n, promised = -(-n * up // down), -(-promised * up // down)  # resample_poly: ceil(n * up / down)
+    return (n, promised) if with_promise else n
 
 
 _HQ_FILTERS = {}

@@ -67,25 +67,41 @@ def gather_objects(obj, group=None):
     return out
 
 
+_PINNED = None      # the core slice pin_rank_cpus gave this process (None: not pinned)
+
+
 def default_io_threads(world=1, cores=None):
-    """Decode / encode workers per rank of a folder job: the host's cores / (2 * ranks on this node), between 2 and 8 --
-    eight ranks x eight workers (the single-rank default) would fight over a 64-core host while the workers of one
-    rank need about 0.3 worker-seconds per 2560 s of audio (profiles/r04_folder_256x10s.json)."""
+    """Decode / encode workers per rank of a folder job, between 2 and 8: half of the cores this RANK has.  After
+    ``pin_rank_cpus`` that is half of the rank's own slice (the slice is already cores / ranks-on-this-node: dividing it by the
+    world size again, as round 5 did, left every multi-rank job at the minimum of 2); unpinned, the host's cores /
+    (2 * ranks on this node) -- LOCAL_WORLD_SIZE when a launcher set it, else ``world``.  Eight ranks x eight workers would
+    fight over a 64-core host while one rank's workers need about 0.3 worker-seconds per 2560 s of audio
+    (profiles/r04_folder_256x10s.json).  ``cores``: the host's core count, for tests (treated as unpinned)."""
     import os
+    if cores is None and _PINNED is not None:
+        return max(2, min(8, len(_PINNED) // 2))
     if cores is None:
         try:
             cores = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             cores = os.cpu_count() or 8
-    return max(2, min(8, cores // (2 * max(1, int(world)))))
+    try:
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", "") or world)
+    except ValueError:
+        local_world = world
+    return max(2, min(8, cores // (2 * max(1, int(local_world)))))
 
 
 def pin_rank_cpus(local_rank, local_world):
     """Give rank ``local_rank`` of ``local_world`` on this node its own contiguous slice of the cores this process may
-    run on (sched_setaffinity), so the ranks' interpreter threads and I/O workers do not migrate across each other's
-    caches.  Returns the slice (list of core ids), or None when there is nothing to split (one rank, fewer cores than
-    ranks, no affinity API)."""
+    run on, so the ranks' interpreter threads and I/O workers do not migrate across each other's caches.  Call it BEFORE
+    ``init_process_group`` and before the first torch operator: ``sched_setaffinity(0, ...)`` binds the calling thread, and
+    only threads created AFTERWARDS (gloo / RCCL progress threads, ATen's intra-op pool, the I/O workers) inherit the mask;
+    ``torch.set_num_threads`` is set to the slice so that CPU operators do not run a host's worth of threads on it.
+    Returns the slice (list of core ids), or None when there is nothing to split (one rank, fewer cores than ranks, no
+    affinity API)."""
     import os
+    global _PINNED
     try:
         cores = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
@@ -99,7 +115,33 @@ def pin_rank_cpus(local_rank, local_world):
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
+    _PINNED = mine
+    try:
+        torch.set_num_threads(max(1, len(mine)))
+    except RuntimeError:
+        pass
     return mine
+
+
+def agree_on_scan(scanned, group=None):
+    """Every rank scanned the folder's headers on its own; a transient read error on ONE rank (a network file system) would give
+    the ranks different work lists and different deals -- files restored twice or by nobody.  All-gather the per-rank
+    ``[(length | None, reason | None), ...]`` lists and keep, for every file, rank 0's answer unless some rank could not read
+    it (then the file is unusable for everybody, with that rank's reason): all ranks deal from the same list.  World size 1 /
+    no process group: the list comes back unchanged."""
+    every = gather_objects(list(scanned), group)
+    if len(every) == 1:
+        return list(scanned)
+    if any(len(e) != len(every[0]) for e in every):
+        raise RuntimeError("the ranks list different folders (%s files)" % ", ".join(str(len(e)) for e in every))
+    out = []
+    for i in range(len(every[0])):
+        bad = next(((r, e[i][1]) for r, e in enumerate(every) if e[i][1] is not None), None)
+        if bad is not None:
+            out.append((None, bad[1] if bad[0] == 0 else "rank %d: %s" % bad))
+        else:
+            out.append((min(e[i][0] for e in every), None))
+    return out
 
 
 def free_port():

@@ -81,14 +81,14 @@ def _wpair(w_packed, device):
     return _dev(w_packed, device), _dev(packing.pack_direct(w_packed), device)
 
 
-import os as _os
-# development switches: VFX_FUSE=0 runs every ResStack layer as two launches, VFX_CONVW=0 (read by the library)
+from ._dev import dev_env as _dev_env
+# development switches (honoured under VFX_DEV=1 only, _dev.py): VFX_FUSE=0 runs every ResStack layer as two launches, VFX_CONVW=0 (read by the library)
 # keeps every launch on the first-generation kernel
-_FUSE = _os.environ.get("VFX_FUSE", "1") != "0"
+_FUSE = _dev_env("VFX_FUSE", "1") != "0"
 # The C = 64 layers with dilation >= 81 run as TWO Winograd F(4,3) launches (convwg4_kernel), in place, instead of the fused layer whose dilated
 # half is a direct sum there (a block of 4 d positions does not fit its tile): 18 GB instead of 10 GB through HBM per layer, but half the
 # products in the dilated half -- step 219.2 -> 217.6 ms alternating on one box (VFX_UNFUSE_WIDE=0 restores the fused form).
-_UNFUSE_WIDE = _os.environ.get("VFX_UNFUSE_WIDE", "1") != "0"
+_UNFUSE_WIDE = _dev_env("VFX_UNFUSE_WIDE", "1") != "0"
 FUSE_MAX_C = 128  # ResStack stages with at most this many channels CAN run one fused launch per layer
 # ResStack stages with at least this many channels run their two k = 3 convolutions per layer as two Winograd F(4,3)
 # launches (convwg4_kernel: half the fp32 MFMAs of the direct sum; the dilation-1 one moves its quads as 16-byte
@@ -97,8 +97,8 @@ FUSE_MAX_C = 128  # ResStack stages with at most this many channels CAN run one 
 # second launch reads the intermediate AND the residual from HBM) -- so C = 64 keeps the fused layer, whose dilation-1
 # half then moved to F(4,3) on the LDS tile as well (229.0 -> 223.5 ms; F(2,3) is its fallback for unaligned rows).
 # VFX_WINO_MIN_C=64 / 0: development switch.
-WINO_MIN_C = int(_os.environ.get("VFX_WINO_MIN_C", "128"))
-WINO2D = _os.environ.get("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
+WINO_MIN_C = int(_dev_env("VFX_WINO_MIN_C", "128"))
+WINO2D = _dev_env("VFX_WINO2D", "1") != "0"       # the 3x3 convolutions of the ResUNet as Winograd F(4,3) (development switch)
 
 
 # Run-time arithmetic switch (voicefixer_amd/selfcheck.py): False = no launch is offered its Winograd-transformed weights, so

@@ -30,6 +30,8 @@ import struct
 
 import numpy as np
 
+from ._dev import dev_env
+
 
 class FlacError(RuntimeError):
     pass
@@ -76,7 +78,7 @@ def native():
 
 def _load_native():
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvfx_audio.so")
-    if os.environ.get("VFX_FLAC_NATIVE", "1") == "0" or not os.path.exists(path):
+    if dev_env("VFX_FLAC_NATIVE", "1") == "0" or not os.path.exists(path):
         return None
     h = ctypes.CDLL(path)
     u8p, i32p = ctypes.POINTER(ctypes.c_ubyte), ctypes.POINTER(ctypes.c_int)
