@@ -17,22 +17,32 @@ batches (utterances shard embarrassingly; no data-path collective): weak scaling
 ``value`` = all ranks' audio seconds / max-over-ranks wall time.
 
 ``host_to_host`` (same JSON line) is the metric as SURVEY.md 8(d) defines it: pinned host waveforms in,
-pinned host waveforms out, H2D of batch k+1 and D2H of batch k-1 on copy streams overlapping the compute of
-batch k (double buffered), everything inside the timed region.  The bench contract defines ``value`` with the inputs
-already resident in HBM ("the PCIe-inclusive rate ... is never value"); the host-to-host figure therefore sits beside
-it as ``value_host_to_host`` (the two differ by < 1 %: the copies hide behind the compute).
+pinned host waveforms out, H2D and D2H on copy streams, the compute alternating over the same HIP streams as the timed
+region, everything inside the timed region.  The host runs up to THREE steps ahead of the oldest unfinished D2H (three slots of
+pinned input / output and device input, what ``VoiceFixer.restore_batches`` keeps in flight: one batch per stream running and one
+queued) and never synchronises on the issue path, so two batches overlap on the device as they do in the resident loop.  The bench
+contract defines ``value`` with the inputs already resident in HBM ("the PCIe-inclusive rate ... is never value"); the host-to-host
+figure therefore sits beside it as ``value_host_to_host``.
 
 ``--scatter`` (BASELINE configs[3], launched under torch.distributed.run): rank 0 owns 256 x N utterances,
 ``dist.restore_sharded`` scatters them over RCCL (backend "nccl"), every rank restores its 256 in batches of
 ``--batch``, rank 0 gathers; the JSON line then reports the whole job (scatter + compute + gather).
 
 The JSON line also carries
-  roofline      -- the dominant kernel (one conv_taps_kernel<BM,BL,..,KC> instance): algorithmic
-                   FLOPs per launch / average launch duration from HIP events on the launch
-                   stream, against the 157.3 TFLOP/s fp32-MFMA peak;
+  roofline      -- the dominant kernel FAMILY (what one regex over rocprofv3's kernel names selects; at batch 32 the
+                   Winograd F(4,3) ResStack convolutions convwg4[p]_kernel<4,1,...>): executed FLOPs per launch / average
+                   launch duration from HIP events on the launch stream (single-stream leg: un-overlapped durations),
+                   against the 157.3 TFLOP/s fp32-MFMA peak at 2.4 GHz; ``traffic`` from the committed PMC passes;
+  clocks        -- shader clock and socket power sampled (sysfs hwmon, else rocm-smi) DURING the timed region and during the
+                   single-stream leg: the dominant kernels run at the 1400 W power cap and the clock the firmware grants under it
+                   differs per chip (2.07-2.26 GHz seen), so a round-over-round delta below ~6 % is only readable next to these;
   cpu_baseline  -- the CPU oracle (oracle/oracle.py, a port of the reference path onto the same
                    torch-CPU operators) timed on this box's host cores on ONE utterance (rank 0,
-                   N = 1 only).  Test infrastructure used as a reported baseline, never shipped.
+                   N = 1 only); ``reference_over_port`` = the measured time ratio of the reference's own modules to the port
+                   (tools/cpu_reference_vs_port.py, build container, where /root/reference exists).  Test infrastructure
+                   used as a reported baseline, never shipped.
+With N > 1 ranks the line also carries ``one_rank_leg`` (rank 0 alone, the other ranks idle at a barrier, same K steps) and
+``scaling_efficiency_self_measured`` = value / (N x that leg's value): a convenience for reading a log, the driver computes its own.
 """
 import argparse
 import json
@@ -48,7 +58,106 @@ sys.path.insert(0, ROOT)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense (no 2:1 sparsity), same guide
 SR = 44100
-TRAFFIC_PROFILE = "r05_pmc_hbm_traffic_bench_b32.json"  # tools/profile_round.sh -> tools/pmc_summary.py
+TRAFFIC_PROFILE = "r06_pmc_hbm_traffic_bench_b32.json"  # tools/profile_round.sh -> tools/pmc_summary.py
+REFERENCE_VS_PORT = "r06_cpu_reference_vs_port.json"     # tools/cpu_reference_vs_port.py (build container)
+
+
+class ClockSampler:
+    """Shader clock (MHz) and socket power (W) of one device, sampled by a host thread while a timed region runs.  sysfs hwmon
+    (freq1_input = sclk in Hz, power1_input / power1_average in microwatts) when the amdgpu driver exposes it, else
+    ``rocm-smi --showpower --showclocks`` (slower: one sample per ~0.5 s).  Reporting only -- nothing is throttled or set."""
+
+    def __init__(self, dev_index=0, period=0.05):
+        import glob
+        import threading
+        self.period, self.samples, self.source = period, [], None
+        self._stop, self._thread = threading.Event(), None
+        self._freq = self._power = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
+        # (render order = HIP order on these single-GPU boxes; on multi-GPU nodes the index picks the n-th amdgpu hwmon)
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
+        if cards:
+            h = cards[min(dev_index, len(cards) - 1)]
+            self._freq = os.path.join(h, "freq1_input")
+            for nm in ("power1_input", "power1_average"):
+                if os.path.exists(os.path.join(h, nm)):
+                    try:
+                        int(open(os.path.join(h, nm)).read())
+                        self._power = os.path.join(h, nm)
+                        break
+                    except (OSError, ValueError):
+                        pass
+            self.source = "sysfs %s (freq1_input, %s)" % (h, os.path.basename(self._power) if self._power else "no power file")
+        self._smi = None
+        if self._freq is None or self._power is None:
+            import shutil
+            self._smi = shutil.which("rocm-smi") or ("/opt/rocm/bin/rocm-smi" if os.path.exists("/opt/rocm/bin/rocm-smi") else None)
+            if self._smi:
+                self.source = (self.source + " + " if self.source else "") + "rocm-smi --showpower --showclocks -d %d" % dev_index
+                self.period = max(period, 0.4)
+        self.dev_index = dev_index
+
+    def _read(self):
+        sclk = watts = None
+        try:
+            if self._freq:
+                sclk = int(open(self._freq).read()) / 1e6
+            if self._power:
+                watts = int(open(self._power).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        if (sclk is None or watts is None) and self._smi:
+            import re
+            import subprocess
+            try:
+                out = subprocess.run([self._smi, "--showpower", "--showclocks", "-d", str(self.dev_index)],
+                                     capture_output=True, text=True, timeout=5).stdout
+                m = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)Mhz", out)
+                if sclk is None and m:
+                    sclk = float(m.group(1))
+                m = re.search(r"Power \(W\):\s*([0-9.]+)", out)
+                if watts is None and m:
+                    watts = float(m.group(1))
+            except (OSError, subprocess.SubprocessError):
+                pass
+        return sclk, watts
+
+    def __enter__(self):
+        import threading
+        if self.source is None:
+            return self
+        self.samples = []
+
+        def loop():
+            while not self._stop.is_set():
+                self.samples.append((time.perf_counter(),) + self._read())
+                self._stop.wait(self.period)
+
+        self._stop.clear()
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._stop.set()
+            self._thread.join(10)
+            self._thread = None
+        return False
+
+    def summary(self, t0=None, t1=None):
+        """{"sclk_mhz": {mean, min, max, n}, "socket_power_w": {...}, "source"} over the samples taken inside [t0, t1]."""
+        if self.source is None:
+            return {"source": None, "note": "neither sysfs hwmon nor rocm-smi available"}
+        rows = [r for r in self.samples if (t0 is None or r[0] >= t0) and (t1 is None or r[0] <= t1)]
+
+        def stat(vals):
+            vals = [v for v in vals if v is not None]
+            if not vals:
+                return None
+            return {"mean": round(sum(vals) / len(vals), 1), "min": round(min(vals), 1), "max": round(max(vals), 1), "n": len(vals)}
+
+        return {"sclk_mhz": stat([r[1] for r in rows]), "socket_power_w": stat([r[2] for r in rows]), "source": self.source}
 
 
 def synth_batch(batch, n, seed, device):
@@ -127,6 +236,21 @@ def cpu_baseline(args, w1, gpu_out):
                      "voicefixer/__main__.py:187-212, at the best thread count of a sweep over a 2 s clip; median of "
                      "%d repetitions; %.1f s of CPU time for them" % (args.seconds, len(times), sum(times)),
            "rms_vs_gpu": err}
+    # kind = "port": /root/reference cannot travel to the GPU box.  The measured equivalence behind the label: the reference's OWN
+    # modules against this port on the same cores (tools/cpu_reference_vs_port.py, taken in the build container this round)
+    rp = os.path.join(ROOT, "profiles", REFERENCE_VS_PORT)
+    if os.path.exists(rp):
+        try:
+            doc = json.load(open(rp))
+            out["reference_over_port"] = {
+                "time_ratio": round(1.0 / doc["port_over_reference_time"], 4),
+                "reference_x_real_time_estimate": round(out["value"] * doc["port_over_reference_time"], 3),
+                "measured_on": "%s, %d threads (build container, profiles/%s)" % (doc["cpu_model"], doc["threads"], REFERENCE_VS_PORT),
+                "rms_port_vs_reference": doc["rms_port_vs_reference"],
+                "note": "reference time / port time for one 10 s utterance on the same cores; > 1 = the port is the faster, i.e. the more "
+                        "demanding, baseline (it skips the dead UpsampleNet.skip_conv and uses torch.stft)"}
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
+            pass
     if all_threads_s is not None:
         out["all_threads"] = {"value": round(args.seconds / all_threads_s, 3), "cores": default_threads,
                               "seconds": round(all_threads_s, 2)}
@@ -135,56 +259,67 @@ def cpu_baseline(args, w1, gpu_out):
 
 def host_to_host_leg(pipe, args, n, dev, compute_streams=None):
     """SURVEY.md 8(d) / BASELINE.md 4.6: host-resident float32 waveforms -> host-resident float32 waveforms.
-    Pinned buffers, a different batch every step, H2D / compute / D2H on three streams with event hand-offs
-    (input and output double buffered), all inside the timed region."""
+    Pinned buffers, a different batch every step, H2D / compute / D2H on their own streams with event hand-offs, all inside
+    the timed region.  ``len(compute streams) + 1`` slots (pinned input, device input, pinned output) = the number of batches
+    ``VoiceFixer.restore_batches`` keeps in flight (api.py: one per HIP stream running, one more queued): the host issues step
+    i as soon as the D2H of step i - slots has finished -- three steps back with two streams, an event that has long fired
+    -- so two batches always overlap on the device, as in the resident loop.  (Round 5 had two slots and waited for step
+    i - 2 before ISSUING step i: the ~600 launches of a step were then queued while only one batch ran, and the leg
+    measured the single-stream time.)"""
     B, steps = args.batch, max(args.steps, 2)
-    host_in = [synth_batch(B, n, 5000 + 31 * k, "cpu").pin_memory() for k in range(2)]
-    host_out = [torch.empty((B, n), dtype=torch.float32).pin_memory() for _ in range(2)]
-    dev_in = [torch.empty((B, n), device=dev) for _ in range(2)]
-    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
     cs = [st for st in (compute_streams or []) if st is not None] or [main]   # compute alternates over these (the folder job's two)
+    NS = len(cs) + 1
+    host_in = [synth_batch(B, n, 5000 + 31 * k, "cpu").pin_memory() for k in range(NS)]
+    host_out = [torch.empty((B, n), dtype=torch.float32).pin_memory() for _ in range(NS)]
+    dev_in = [torch.empty((B, n), device=dev) for _ in range(NS)]
+    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     pipe.set_streams(len(cs))
-    ev_in = [torch.cuda.Event() for _ in range(2)]     # H2D of slot k finished
-    ev_free = [torch.cuda.Event() for _ in range(2)]   # compute has consumed dev_in[k]
-    ev_done = [torch.cuda.Event() for _ in range(2)]   # D2H of slot k finished
-    keep = [None, None]
+    ev_in = [torch.cuda.Event() for _ in range(NS)]     # H2D of slot k finished
+    ev_y = [torch.cuda.Event() for _ in range(NS)]      # compute of slot k finished (dev_in[k] consumed, result ready)
+    ev_done = [torch.cuda.Event() for _ in range(NS)]   # D2H of slot k finished
+    keep = [None] * NS
+    waited = [0.0]
 
     def run(k_steps):
         for i in range(k_steps):
-            k = i % 2
+            k = i % NS
+            if i >= NS:
+                t = time.perf_counter()
+                ev_done[k].synchronize()     # host_out[k] is free again: the D2H of step i - NS (bounds the run-ahead, as restore_batches does)
+                waited[0] += time.perf_counter() - t
             with torch.cuda.stream(s_in):
-                if i >= 2:
-                    s_in.wait_event(ev_free[k])
+                if i >= NS:
+                    s_in.wait_event(ev_y[k])
                 dev_in[k].copy_(host_in[k], non_blocking=True)
                 ev_in[k].record(s_in)
             c = cs[i % len(cs)]
             c.wait_event(ev_in[k])
             with torch.cuda.stream(c):
                 y = pipe.restore(dev_in[k], n)
-            ev_free[k].record(c)
-            ev_y = torch.cuda.Event()
-            ev_y.record(c)
+            ev_y[k].record(c)
             with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_y)
-                if i >= 2:
-                    ev_done[k].synchronize()  # host_out[k] is free again (bounds the host's run-ahead to two steps)
+                s_out.wait_event(ev_y[k])
                 host_out[k].copy_(y, non_blocking=True)
                 ev_done[k].record(s_out)
-            keep[k] = y  # keep the device result alive until its D2H has been issued and finished
+            y.record_stream(s_out)
+            keep[k] = y  # (and the device result stays referenced until its slot comes round again)
         torch.cuda.synchronize()
 
-    run(2)
+    run(NS)
+    waited[0] = 0.0
     t0 = time.perf_counter()
     run(steps)
     dt = time.perf_counter() - t0
     pipe.check()
-    assert torch.isfinite(host_out[0]).all() and torch.isfinite(host_out[1]).all()
+    assert all(torch.isfinite(h).all() for h in host_out)
     return {"value": round(B * args.seconds * steps / dt, 2), "unit": "x real-time",
-            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "compute_streams": len(cs),
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "compute_streams": len(cs), "slots_in_flight": NS,
+            "host_waited_for_a_free_slot_s": round(waited[0], 4),
             "pcie_bytes_per_step": 2 * B * n * 4,
-            "note": "pinned host waveform -> pinned host waveform, H2D/D2H double buffered on copy streams inside the "
-                    "timed region, a different batch per step (SURVEY.md 8(d)); file decode/encode excluded"}
+            "note": "pinned host waveform -> pinned host waveform, H2D / D2H on copy streams inside the timed region, %d slots in "
+                    "flight (VoiceFixer.restore_batches' depth), a different batch per step (SURVEY.md 8(d)); file decode/encode "
+                    "excluded" % NS}
 
 
 def scatter_job(args, pipe, n, rank, world, dev, dist):
@@ -332,6 +467,13 @@ def folder_job(args, rank, world, dev, dist, dry=False):
     keys = ["files", "audio_s", "wall_s", "decode_worker_s", "encode_worker_s", "device_waited_for_decode_s", "batches"]
     allr = vdist.gather_counters([st[k] for k in keys] + [dt, 0.0 if dry else hbm_ms, float(dev.index) if dev is not None else -1.0],
                                  dev if (dist is not None and not dry and dist.is_initialized() and dist.get_backend() == "nccl") else None)
+    try:
+        my_cores = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        my_cores = []
+    slices = vdist.gather_objects({"cores": "%d-%d" % (my_cores[0], my_cores[-1]) if my_cores else None, "n_cores": len(my_cores),
+                                   "pinned": vdist._PINNED is not None, "io_threads": st.get("io_threads"),
+                                   "torch_threads": torch.get_num_threads()})
     if rank == 0:
         outs = sorted(os.listdir(outd))
         assert len(outs) == int(sum(x[0] for x in allr)) == st["folder_files"], (len(outs), st["folder_files"])
@@ -342,7 +484,8 @@ def folder_job(args, rank, world, dev, dist, dry=False):
         hbm_value = None if dry else world * args.batch * args.seconds / (max(x[8] for x in allr) * 1e-3)
         line = {
             "metric": "seconds-of-44.1kHz-audio restored per wall-second",
-            "value": round(audio / dmax, 2), "unit": "x real-time", "n_gpus": world,
+            # n_gpus counts DISTINCT devices (an --oversubscribe rehearsal puts several ranks on one); `ranks` = processes that ran
+            "value": round(audio / dmax, 2), "unit": "x real-time", "n_gpus": world if dry else len({int(x[9]) for x in allr}), "ranks": world,
             "steps": int(max(x[6] for x in allr)), "warmup": 1, "ms_per_step": round(dmax * 1e3 / max(1, max(x[6] for x in allr)), 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic" if synthetic else "folder",
             "value_definition": "DISK TO DISK: from the folder of PCM16 files on tmpfs to the last restored file written "
@@ -353,7 +496,10 @@ def folder_job(args, rank, world, dev, dist, dry=False):
                                    % (3 if world > 1 else 2, int(sum(x[0] for x in allr)), args.seconds, int(allr[0][0]), args.batch),
                        "batch_per_gpu": args.batch, "utterance_seconds": args.seconds, "io_threads": st.get("io_threads", args.io_threads),
                        "streams": args.folder_streams, "host_cores": os.cpu_count(), "folder": base if synthetic else args.folder,
-                       "parallelism": "files dealt to %d rank(s) by dist.deal_files (no data-path collective; one all-gather of counters)" % world},
+                       "parallelism": "files dealt to %d rank(s) by dist.deal_files (no data-path collective; one all-gather of counters)" % world,
+                       **({"oversubscribed": "%d ranks share %d device(s): a rehearsal of the launch, the deal and the per-rank I/O, NOT a scaling "
+                                             "measurement" % (world, len({int(x[9]) for x in allr}))}
+                          if (not dry and len({int(x[9]) for x in allr}) < world) else {})},
             "hbm_resident": None if dry else {"value": round(hbm_value, 2), "ms_per_step": round(max(x[8] for x in allr), 3)},
             "disk_to_disk_over_hbm_resident": None if dry else round(audio / dmax / hbm_value, 4),
             "decode_worker_s": round(sum(x[3] for x in allr), 3), "encode_worker_s": round(sum(x[4] for x in allr), 3),
@@ -364,7 +510,8 @@ def folder_job(args, rank, world, dev, dist, dry=False):
             **({"dry_run": True} if dry else {}),
             "per_rank": [{"rank": r, "device": "dry" if dry else "cuda:%d" % int(x[9]), "files": int(x[0]), "audio_s": round(x[1], 1), "batches": int(x[6]),
                           "wall_s": round(x[7], 4), "folder_s": round(x[2], 4), "decode_worker_s": round(x[3], 3),
-                          "encode_worker_s": round(x[4], 3), "device_waited_for_decode_s": round(x[5], 4)} for r, x in enumerate(allr)],
+                          "encode_worker_s": round(x[4], 3), "device_waited_for_decode_s": round(x[5], 4),
+                          "cpu": slices[r] if r < len(slices) else None} for r, x in enumerate(allr)],
             "lib_build_id": None if dry else _lib_build_id(),
         }
         _json_line_last(line)
@@ -497,12 +644,20 @@ def main():
         os.dup2(2, 1)   # only rank 0 owns stdout (the JSON line); whatever native libraries print elsewhere goes to stderr
     requested = int(os.environ.get("VFX_BENCH_REQUESTED_GPUS", args.gpus))
     if args.dry_run:
+        if world > 1 and (args.synth_folder or args.folder):
+            from voicefixer_amd import dist as vdist_
+            vdist_.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device("cuda", torch.cuda.current_device())
     dist = None
+    if world > 1 and (args.synth_folder or args.folder):
+        # the folder job runs decode / encode workers next to the interpreter: every rank gets its own core slice, BEFORE the
+        # process group exists (its threads inherit the mask) -- what `python -m voicefixer_amd --gpus N` does (__main__.py)
+        from voicefixer_amd import dist as vdist_
+        vdist_.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world > 1 or args.scatter or ((args.synth_folder or args.folder) and "WORLD_SIZE" in os.environ):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -559,6 +714,20 @@ def main():
         streams = SINGLE
     out = run_steps(args.warmup)
     barrier()
+    # ---- (N > 1 ranks) one-rank leg: rank 0 runs the K steps ALONE while the other ranks wait at the barrier -- the N = 1 rate of
+    # this very job on this very node, so that the line can say what N ranks made of it (no events, same streams)
+    one_rank = None
+    if dist is not None and world > 1:
+        if rank == 0:
+            t1 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            d1 = time.perf_counter() - t1
+            one_rank = {"value": round(args.batch * args.seconds * args.steps / d1, 2), "unit": "x real-time",
+                        "ms_per_step": round(d1 / args.steps * 1e3, 3), "steps": args.steps,
+                        "note": "rank 0 alone on its device, every other rank idle at a barrier; same build, same streams"}
+        barrier()
+    sampler = ClockSampler(dev.index)
     if not args.no_events:
         # pre-created timing events (creating one costs ~10 us of host time: visible in a launch-bound batch-1 run)
         ops.EVENT_POOL = [torch.cuda.Event(enable_timing=True) for _ in range(800 * max(args.steps, 1) * (2 if len(streams) > 1 else 1))]
@@ -566,10 +735,12 @@ def main():
             e.record()  # first use of an event allocates its backing object
         torch.cuda.synchronize()
     ops.PROFILE = None if args.no_events else []
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
+    with sampler:
+        t0 = time.perf_counter()
+        out = run_steps(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+    clocks = {"timed_region": sampler.summary(t0 + 0.25 * dt, t0 + dt)}   # (the first quarter: the clock is still ramping)
     prof, ops.PROFILE = ops.PROFILE, None
     if prof is None:
         ops.EVENT_POOL = None
@@ -587,10 +758,12 @@ def main():
         run_steps(1, SINGLE)
         barrier()
         prof_timed, ops.PROFILE = prof, []
-        t1 = time.perf_counter()
-        run_steps(args.steps, SINGLE)
-        barrier()
-        dt_single = time.perf_counter() - t1
+        with sampler:
+            t1 = time.perf_counter()
+            run_steps(args.steps, SINGLE)
+            barrier()
+            dt_single = time.perf_counter() - t1
+        clocks["single_stream_leg"] = sampler.summary(t1 + 0.25 * dt_single, t1 + dt_single)
         prof, ops.PROFILE = ops.PROFILE, None
         pipe.check()
         pipe.set_streams(len(streams))
@@ -788,7 +961,14 @@ def main():
         "per_rank": per_rank,
         "lib_build_id": build_id,
         "roofline": roofline,
+        "clocks": dict(clocks, note="shader clock / socket power of rank 0's device while the K timed steps ran (first quarter of the "
+                                    "region dropped: ramp).  The convolution families run at the package power cap, so achieved = "
+                                    "busy share x granted clock and boxes differ by what clock the cap buys them (DESIGN.md 3.0): "
+                                    "compare rounds at equal sclk, or normalise by it"),
     }
+    if one_rank is not None:
+        line["one_rank_leg"] = one_rank
+        line["scaling_efficiency_self_measured"] = round(value / (world * one_rank["value"]), 4)
     if dt_single is not None:
         dts = dt_single
         if dist is not None:

@@ -954,11 +954,45 @@ def test_bench_oversubscribed_folder_job_two_ranks_on_one_device(tmp_path):
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     if torch.cuda.device_count() >= 2:
-        assert j["n_gpus"] == 2
+        assert j["n_gpus"] == 2 and j["ranks"] == 2
         return
-    assert j["n_gpus"] == 2 and j["requested_gpus"] == 2 and j["visible_devices"] == 1 and j["rccl"]["backend"] == "gloo"
+    # n_gpus counts DISTINCT devices (a harness parsing n_gpus must not read a rehearsal as an N-GPU result)
+    assert j["n_gpus"] == 1 and j["ranks"] == 2 and "oversubscribed" in j["config"]
+    assert j["requested_gpus"] == 2 and j["visible_devices"] == 1 and j["rccl"]["backend"] == "gloo"
     assert [pr["files"] for pr in j["per_rank"]] == [4, 4] and all(pr["device"] == "cuda:0" for pr in j["per_rank"])
     assert j["value"] > 10 and abs(j["per_rank"][0]["audio_s"] - j["per_rank"][1]["audio_s"]) < 1e-6
+    # every rank reports the core slice it was pinned to (dist.pin_rank_cpus runs before the process group exists)
+    cpus = [pr["cpu"] for pr in j["per_rank"]]
+    assert all(c["n_cores"] >= 1 for c in cpus)
+    if all(c["pinned"] for c in cpus):
+        assert cpus[0]["cores"] != cpus[1]["cores"] and all(c["torch_threads"] == c["n_cores"] for c in cpus)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (the first real N > 1 run: lights up on a multi-GPU lease)")
+def test_bench_two_devices_on_rccl_folder_and_weak_scaling_lines():
+    """On a node with >= 2 GPUs: ``bench.py --gpus 2 --synth-folder 32`` (BASELINE configs[3] disk to disk, RCCL for the counters) and
+    ``bench.py --gpus 2`` (the weak-scaling line the driver runs) -- one rank per device, backend nccl, every file written once,
+    and the second line carries the one-rank leg + the self-measured efficiency."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def line(argv):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + argv, cwd=root, capture_output=True, text=True, timeout=1800,
+                           env=dict(os.environ, PYTHONPATH=root))
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    j = line(["--gpus", "2", "--synth-folder", "32", "--batch", "16", "--steps", "2"])
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["rccl"] == {"backend": "nccl", "world_size": 2}
+    assert sorted(pr["device"] for pr in j["per_rank"]) == ["cuda:0", "cuda:1"] and [pr["files"] for pr in j["per_rank"]] == [32, 32]
+    assert all(pr["cpu"]["pinned"] for pr in j["per_rank"]) or os.cpu_count() < 4
+    j = line(["--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "8", "--no-bf16x3"])
+    assert j["n_gpus"] == 2 and j["rccl"]["backend"] == "nccl" and sorted(pr["device"] for pr in j["per_rank"]) == ["cuda:0", "cuda:1"]
+    assert j["one_rank_leg"]["value"] > 0 and 0.5 < j["scaling_efficiency_self_measured"] < 1.2
 
 
 def test_graph_replays_survive_an_eager_pass_in_between(seeded_states):

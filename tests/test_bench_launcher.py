@@ -56,4 +56,10 @@ def test_folder_job_on_two_ranks_with_a_stub_device_stage():
     assert sum(files) == 10 and files == [5, 5] and [r["rank"] for r in line["per_rank"]] == [0, 1]
     assert abs(sum(r["audio_s"] for r in line["per_rank"]) - 10 * 0.25) < 0.11 and line["value"] > 0
     assert all(r["decode_worker_s"] > 0 and r["encode_worker_s"] > 0 and r["batches"] == 2 for r in line["per_rank"])
-    assert "configs[3]" in line["config"]["workload"] and line["hbm_resident"] is None
+    assert "configs[3]" in line["config"]["workload"] and line["hbm_resident"] is None and line["ranks"] == 2
+    # the ranks of the folder job are pinned to disjoint core slices before their process group exists, and
+    # their I/O pools / ATen pools are sized to the slice
+    cpus = [r["cpu"] for r in line["per_rank"]]
+    if len(os.sched_getaffinity(0)) >= 4:
+        assert all(c["pinned"] for c in cpus) and cpus[0]["cores"] != cpus[1]["cores"]
+        assert all(c["torch_threads"] == c["n_cores"] for c in cpus)
