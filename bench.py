@@ -74,10 +74,18 @@ class ClockSampler:
         self._stop, self._thread = threading.Event(), None
         self._freq = self._power = None
         cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*"))
-        # (render order = HIP order on these single-GPU boxes; on multi-GPU nodes the index picks the n-th amdgpu hwmon)
         cards = [c for c in cards if os.path.exists(os.path.join(c, "freq1_input"))]
-        if cards:
-            h = cards[min(dev_index, len(cards) - 1)]
+        # the HIP device's sysfs card by PCI address: a box may show more cards in sysfs than the process may use (a one-GPU lease
+        # of an eight-GPU node), and HIP index 0 is not card0 then
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except (AttributeError, RuntimeError, AssertionError):
+            pass
+        match = [c for c in cards if want and os.path.basename(os.path.realpath(os.path.join(c, "..", ".."))) == want]
+        if match or (cards and len(cards) == 1):
+            h = (match or cards)[0]
             self._freq = os.path.join(h, "freq1_input")
             for nm in ("power1_input", "power1_average"):
                 if os.path.exists(os.path.join(h, nm)):
@@ -257,69 +265,45 @@ def cpu_baseline(args, w1, gpu_out):
     return out
 
 
-def host_to_host_leg(pipe, args, n, dev, compute_streams=None):
-    """SURVEY.md 8(d) / BASELINE.md 4.6: host-resident float32 waveforms -> host-resident float32 waveforms.
-    Pinned buffers, a different batch every step, H2D / compute / D2H on their own streams with event hand-offs, all inside
-    the timed region.  ``len(compute streams) + 1`` slots (pinned input, device input, pinned output) = the number of batches
-    ``VoiceFixer.restore_batches`` keeps in flight (api.py: one per HIP stream running, one more queued): the host issues step
-    i as soon as the D2H of step i - slots has finished -- three steps back with two streams, an event that has long fired
-    -- so two batches always overlap on the device, as in the resident loop.  (Round 5 had two slots and waited for step
-    i - 2 before ISSUING step i: the ~600 launches of a step were then queued while only one batch ran, and the leg
-    measured the single-stream time.)"""
+def host_to_host_leg(vf, args, n, dev, n_streams, stream_pool=None):
+    """SURVEY.md 8(d) / BASELINE.md 4.6: host-resident float32 waveforms -> host-resident float32 waveforms, through the PRODUCT's
+    own device stage: ``VoiceFixer.restore_batches`` (api.py) fed with pinned (B, n) batches, a different batch every step.  Per
+    batch it queues H2D, the ~600 launches and the D2H into a pinned result ON THE BATCH'S COMPUTE STREAM (no copy streams: with
+    five streams on the runtime's four hardware queues a copy stream's event wait shares a queue with -- and stalls -- a compute
+    stream, which is how round 5's hand-rolled leg lost the two-stream gain), batches alternate over ``n_streams`` HIP streams
+    and the host runs ``n_streams + 1`` batches ahead.  Everything inside the timed region; file decode / encode excluded (the
+    disk-to-disk figure is ``--synth-folder``)."""
     B, steps = args.batch, max(args.steps, 2)
-    main = torch.cuda.current_stream(dev)
-    cs = [st for st in (compute_streams or []) if st is not None] or [main]   # compute alternates over these (the folder job's two)
-    NS = len(cs) + 1
+    NS = n_streams + 2
+    if stream_pool:        # the HIP streams of the timed region (a process that keeps creating streams ends up with several of them on
+        vf._stream_pool = list(stream_pool)     # one of the runtime's four hardware queues, where they serialise)
     host_in = [synth_batch(B, n, 5000 + 31 * k, "cpu").pin_memory() for k in range(NS)]
-    host_out = [torch.empty((B, n), dtype=torch.float32).pin_memory() for _ in range(NS)]
-    dev_in = [torch.empty((B, n), device=dev) for _ in range(NS)]
-    s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-    pipe.set_streams(len(cs))
-    ev_in = [torch.cuda.Event() for _ in range(NS)]     # H2D of slot k finished
-    ev_y = [torch.cuda.Event() for _ in range(NS)]      # compute of slot k finished (dev_in[k] consumed, result ready)
-    ev_done = [torch.cuda.Event() for _ in range(NS)]   # D2H of slot k finished
-    keep = [None] * NS
-    waited = [0.0]
+    lens = [n] * B
 
-    def run(k_steps):
-        for i in range(k_steps):
-            k = i % NS
-            if i >= NS:
-                t = time.perf_counter()
-                ev_done[k].synchronize()     # host_out[k] is free again: the D2H of step i - NS (bounds the run-ahead, as restore_batches does)
-                waited[0] += time.perf_counter() - t
-            with torch.cuda.stream(s_in):
-                if i >= NS:
-                    s_in.wait_event(ev_y[k])
-                dev_in[k].copy_(host_in[k], non_blocking=True)
-                ev_in[k].record(s_in)
-            c = cs[i % len(cs)]
-            c.wait_event(ev_in[k])
-            with torch.cuda.stream(c):
-                y = pipe.restore(dev_in[k], n)
-            ev_y[k].record(c)
-            with torch.cuda.stream(s_out):
-                s_out.wait_event(ev_y[k])
-                host_out[k].copy_(y, non_blocking=True)
-                ev_done[k].record(s_out)
-            y.record_stream(s_out)
-            keep[k] = y  # (and the device result stays referenced until its slot comes round again)
-        torch.cuda.synchronize()
+    def feed(k):
+        for i in range(k):
+            yield i, "ragged", host_in[i % NS], lens
+
+    def run(k):
+        seen, last = 0, None
+        for tag, out_host, lens_out in vf.restore_batches(feed(k), streams=n_streams):
+            assert tag == seen and out_host.shape == (B, n)
+            seen, last = seen + 1, out_host
+        assert seen == k
+        return last
 
     run(NS)
-    waited[0] = 0.0
     t0 = time.perf_counter()
-    run(steps)
+    last = run(steps)
     dt = time.perf_counter() - t0
-    pipe.check()
-    assert all(torch.isfinite(h).all() for h in host_out)
+    assert torch.isfinite(last).all() and float(last.abs().max()) > 1e-3
     return {"value": round(B * args.seconds * steps / dt, 2), "unit": "x real-time",
-            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "compute_streams": len(cs), "slots_in_flight": NS,
-            "host_waited_for_a_free_slot_s": round(waited[0], 4),
+            "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps, "compute_streams": n_streams, "batches_in_flight": n_streams + 1,
             "pcie_bytes_per_step": 2 * B * n * 4,
-            "note": "pinned host waveform -> pinned host waveform, H2D / D2H on copy streams inside the timed region, %d slots in "
-                    "flight (VoiceFixer.restore_batches' depth), a different batch per step (SURVEY.md 8(d)); file decode/encode "
-                    "excluded" % NS}
+            "note": "pinned host waveform -> pinned host waveform through VoiceFixer.restore_batches (the folder job's device stage: H2D, "
+                    "launches and D2H of a batch on its own compute stream, %d streams, the host %d batches ahead), a different batch per "
+                    "step, the generator's start-up and drain inside the timed region (SURVEY.md 8(d)); file decode/encode excluded"
+                    % (n_streams, n_streams + 1)}
 
 
 def scatter_job(args, pipe, n, rank, world, dev, dist):
@@ -433,10 +417,17 @@ def folder_job(args, rank, world, dev, dist, dry=False):
     else:
         vf = VoiceFixer.from_state(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321))
         pipe = vf._get_pipe()
+    def stamp(what, t):
+        print("bench.py: [%s] rank %d: %s %.1f s" % (time.strftime("%H:%M:%S"), rank, what, time.perf_counter() - t), file=sys.stderr, flush=True)
+
+    t_ = time.perf_counter()
     barrier()      # (rank 0 has written the folders)
+    stamp("pipeline built, folders ready after", t_)
     ext = (".wav", ".flac") if args.folder else (".wav",)
+    t_ = time.perf_counter()
     vf.restore_folder(warm_in, warm_out, batch_size=args.batch, io_threads=args.io_threads or None, rank=rank, world=world, extensions=ext)
     barrier()
+    stamp("warm-up folder", t_)
     st = {}
     t0 = time.perf_counter()
     vf.restore_folder(ind, outd, batch_size=args.batch, io_threads=args.io_threads or None, rank=rank, world=world, stats=st,
@@ -471,7 +462,7 @@ def folder_job(args, rank, world, dev, dist, dry=False):
         my_cores = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         my_cores = []
-    slices = vdist.gather_objects({"cores": "%d-%d" % (my_cores[0], my_cores[-1]) if my_cores else None, "n_cores": len(my_cores),
+    slices = vdist.gather_objects({"cores": _ranges(my_cores), "n_cores": len(my_cores), "n_physical": len(vdist.physical_cores(my_cores)),
                                    "pinned": vdist._PINNED is not None, "io_threads": st.get("io_threads"),
                                    "torch_threads": torch.get_num_threads()})
     if rank == 0:
@@ -518,6 +509,18 @@ def folder_job(args, rank, world, dev, dist, dry=False):
         shutil.rmtree(base, ignore_errors=True)
     if dist is not None and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def _ranges(ids):
+    """[0, 1, 2, 3, 128, 129] -> "0-3,128-129" (a rank's logical CPUs: its physical cores and their SMT siblings)."""
+    out, i = [], 0
+    while i < len(ids):
+        j = i
+        while j + 1 < len(ids) and ids[j + 1] == ids[j] + 1:
+            j += 1
+        out.append(str(ids[i]) if i == j else "%d-%d" % (ids[i], ids[j]))
+        i = j + 1
+    return ",".join(out) or None
 
 
 def _lib_build_id():
@@ -633,7 +636,12 @@ def main():
                          "counters) -- a rehearsal of the N-rank folder job, not a scaling measurement")
     ap.add_argument("--dry-run", action="store_true",
                     help="test hook: rehearse the N-rank launch on CPU (gloo, no device work)")
+    ap.add_argument("--dump-stacks-after", type=float, default=0.0,
+                    help="development: faulthandler dumps every thread's stack to stderr after this many seconds (where is a slow run?)")
     args = ap.parse_args()
+    if args.dump_stacks_after > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.dump_stacks_after, repeat=True, file=sys.stderr)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])   # does not return when it re-executes under torch.distributed.run
@@ -675,7 +683,13 @@ def main():
     build_id = _lib.lib().vfx_build_id().decode()
 
     n = int(round(args.seconds * SR))
-    pipe = engine.Pipeline(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321), dev, args.math)
+    # the product's facade owns the pipeline (VoiceFixer.restore_batches is the host-to-host leg's device stage); the resident legs
+    # drive its engine directly
+    from voicefixer_amd.api import VoiceFixer
+    vf = VoiceFixer.from_state(weights.seeded_vocoder_state(1234), weights.seeded_restorer_state(4321))
+    vf.math = args.math
+    pipe = vf._get_pipe()
+    assert isinstance(pipe, engine.Pipeline) and pipe.device == dev, (pipe.device, dev)
     if args.scatter:
         return scatter_job(args, pipe, n, rank, world, dev, dist)
     if args.graph:
@@ -1002,7 +1016,8 @@ def main():
             "note": "opt-in VoiceFixer.set_math('bf16x3'); parity bound 1e-3 RMS"}
 
     if world == 1 and not args.no_host_leg:
-        line["host_to_host"] = host_to_host_leg(pipe, args, n, dev, streams)
+        real = [st for st in streams if st is not None]
+        line["host_to_host"] = host_to_host_leg(vf, args, n, dev, len(real) or 1, real)
         # SURVEY.md 8(d)'s host-waveform -> host-waveform figure, at the top level next to `value` (which the bench
         # contract defines with inputs resident in HBM)
         line["value_host_to_host"] = line["host_to_host"]["value"]

@@ -62,4 +62,4 @@ def test_folder_job_on_two_ranks_with_a_stub_device_stage():
     cpus = [r["cpu"] for r in line["per_rank"]]
     if len(os.sched_getaffinity(0)) >= 4:
         assert all(c["pinned"] for c in cpus) and cpus[0]["cores"] != cpus[1]["cores"]
-        assert all(c["torch_threads"] == c["n_cores"] for c in cpus)
+        assert all(c["torch_threads"] == min(c["n_physical"], 16) for c in cpus)

@@ -377,24 +377,45 @@ def test_io_thread_default_and_cpu_slices():
         vdist._PINNED = None
 
 
-def _pin_worker(q):
+def _smt(c):      # a host whose logical CPUs n/2 .. n-1 are the SMT siblings of 0 .. n/2-1 (Linux's numbering on the GPU boxes)
+    n = len(os.sched_getaffinity(0)) // 2 * 2
+    return "%d,%d" % (c % (n // 2), c % (n // 2) + n // 2) if c < n else str(c)
+
+
+def _pin_worker(q, smt):
     import torch as t
-    mine = vdist.pin_rank_cpus(1, 2)
+    mine = vdist.pin_rank_cpus(1, 2, _smt if smt else None)
     q.put((mine, sorted(os.sched_getaffinity(0)), t.get_num_threads(), vdist.default_io_threads(2)))
 
 
-def test_pin_rank_cpus_binds_the_slice_and_sizes_the_thread_pools():
+@pytest.mark.parametrize("smt", [False, True])
+def test_pin_rank_cpus_binds_the_slice_and_sizes_the_thread_pools(smt):
+    """Round 6: the slice is cut in PHYSICAL cores.  With the SMT numbering of the GPU boxes (siblings of 0..N-1 are N..2N-1) a
+    contiguous cut of logical ids gave rank 1 the hardware threads of rank 0's cores."""
     cores = sorted(os.sched_getaffinity(0))
-    if len(cores) < 4:
-        pytest.skip("needs four cores")
+    if len(cores) < 8:
+        pytest.skip("needs eight cores")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_pin_worker, args=(q,))
+    p = ctx.Process(target=_pin_worker, args=(q, smt))
     p.start()
     mine, aff, nthreads, io = q.get(timeout=120)
     p.join(60)
-    lo, hi = vdist.shard_range(len(cores), 1, 2)
-    assert mine == aff == cores[lo:hi] and nthreads == len(mine) and io == max(2, min(8, len(mine) // 2))
+    assert mine == aff
+    if smt:
+        n = len(cores) // 2 * 2
+        phys = [(cores[i], cores[i + n // 2]) for i in range(n // 2)]       # what _smt describes (cores = 0..n-1 here)
+        lo, hi = vdist.shard_range(len(phys), 1, 2)
+        assert mine == sorted(c for pr in phys[lo:hi] for c in pr)
+        assert nthreads == hi - lo and io == max(2, (hi - lo) // 2)
+        # ... and rank 0's slice shares no physical core with it
+        lo0, hi0 = vdist.shard_range(len(phys), 0, 2)
+        assert not {c for pr in phys[lo0:hi0] for c in pr} & set(mine)
+    else:
+        lo, hi = vdist.shard_range(len(cores), 1, 2)
+        assert mine == cores[lo:hi] and nthreads == min(len(mine), vdist.MAX_RANK_TORCH_THREADS) and io == max(2, min(8, len(mine) // 2))
+    assert vdist.physical_cores([0, 1, 2, 3, 4, 5, 6, 7], lambda c: "%d,%d" % (c % 4, c % 4 + 4)) == [(0, 4), (1, 5), (2, 6), (3, 7)]
+    assert vdist.physical_cores([1, 5, 6], lambda c: "%d,%d" % (c % 4, c % 4 + 4)) == [(1, 5), (6,)]
 
 
 def _scan_worker(rank, world, port, q):

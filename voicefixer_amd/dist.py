@@ -79,7 +79,7 @@ def default_io_threads(world=1, cores=None):
     (profiles/r04_folder_256x10s.json).  ``cores``: the host's core count, for tests (treated as unpinned)."""
     import os
     if cores is None and _PINNED is not None:
-        return max(2, min(8, len(_PINNED) // 2))
+        return max(2, min(8, len(physical_cores(_PINNED)) // 2))
     if cores is None:
         try:
             cores = len(os.sched_getaffinity(0))
@@ -92,32 +92,70 @@ def default_io_threads(world=1, cores=None):
     return max(2, min(8, cores // (2 * max(1, int(local_world)))))
 
 
-def pin_rank_cpus(local_rank, local_world):
-    """Give rank ``local_rank`` of ``local_world`` on this node its own contiguous slice of the cores this process may
-    run on, so the ranks' interpreter threads and I/O workers do not migrate across each other's caches.  Call it BEFORE
-    ``init_process_group`` and before the first torch operator: ``sched_setaffinity(0, ...)`` binds the calling thread, and
-    only threads created AFTERWARDS (gloo / RCCL progress threads, ATen's intra-op pool, the I/O workers) inherit the mask;
-    ``torch.set_num_threads`` is set to the slice so that CPU operators do not run a host's worth of threads on it.
-    Returns the slice (list of core ids), or None when there is nothing to split (one rank, fewer cores than ranks, no
-    affinity API)."""
+def physical_cores(cpus, read_siblings=None):
+    """Group the logical CPUs ``cpus`` by physical core (sysfs ``topology/thread_siblings_list``): a sorted list of tuples, one
+    per core, each holding that core's hardware threads that are in ``cpus``.  Without sysfs every CPU is its own core.
+    ``read_siblings(cpu) -> "0,128"`` replaces the sysfs read (tests)."""
+    seen, cores = set(), []
+    allowed = set(cpus)
+    for c in sorted(cpus):
+        if c in seen:
+            continue
+        sib = [c]
+        try:
+            if read_siblings is not None:
+                txt = read_siblings(c)
+            else:
+                with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                    txt = f.read().strip()
+            sib = []
+            for part in txt.split(","):
+                a, _, b = part.partition("-")
+                sib.extend(range(int(a), int(b or a) + 1))
+            sib = sorted(x for x in sib if x in allowed) or [c]
+        except (OSError, ValueError):
+            sib = [c]
+        seen.update(sib)
+        cores.append(tuple(sib))
+    return sorted(cores)
+
+
+MAX_RANK_TORCH_THREADS = 16    # ATen's intra-op pool of a rank: this path's host-side torch work (weight packing at load, batch staging)
+                               # is many small operators -- 16 threads is the fastest count on the GPU boxes' 2 x 64-core host
+                               # (bench.py cpu_baseline.thread_sweep: 16 beats 32, 64 and 128), and a rank's slice is smaller anyway
+
+
+def pin_rank_cpus(local_rank, local_world, read_siblings=None):
+    """Give rank ``local_rank`` of ``local_world`` on this node its own slice of the cores this process may run on, so the ranks'
+    interpreter threads and I/O workers do not migrate across each other's caches.  The slice is cut in PHYSICAL cores (both
+    hardware threads of a core go to the same rank): Linux numbers the SMT siblings of cores 0..N-1 as N..2N-1, so a contiguous
+    cut of the logical ids -- what round 5 did -- hands rank 1 of 2 exactly the siblings of rank 0's cores, and two OpenMP pools
+    spinning on the same physical cores made the weight packing at load take minutes instead of seconds (measured on the
+    2 x 64-core GPU box: `bench.py --gpus 2 --oversubscribe` 7 min -> see profiles/README.md, round 6).
+    Call it BEFORE ``init_process_group`` and before the first torch operator: ``sched_setaffinity(0, ...)`` binds the calling
+    thread, and only threads created AFTERWARDS (gloo / RCCL progress threads, ATen's intra-op pool, the I/O workers) inherit the
+    mask; ``torch.set_num_threads`` is set to the slice's physical cores, at most MAX_RANK_TORCH_THREADS.
+    Returns the slice (sorted list of logical core ids), or None when there is nothing to split (one rank, fewer physical cores
+    than 2 per rank, no affinity API)."""
     import os
     global _PINNED
     try:
-        cores = sorted(os.sched_getaffinity(0))
+        cpus = sorted(os.sched_getaffinity(0))
     except (AttributeError, OSError):
         return None
     local_world = int(local_world)
+    cores = physical_cores(cpus, read_siblings)
     if local_world <= 1 or len(cores) < 2 * local_world:
         return None
     lo, hi = shard_range(len(cores), int(local_rank), local_world)
-    mine = cores[lo:hi]
+    mine = sorted(c for core in cores[lo:hi] for c in core)
     try:
         os.sched_setaffinity(0, mine)
     except OSError:
         return None
     _PINNED = mine
     try:
-        torch.set_num_threads(max(1, len(mine)))
+        torch.set_num_threads(max(1, min(hi - lo, MAX_RANK_TORCH_THREADS)))
     except RuntimeError:
         pass
     return mine
