@@ -388,7 +388,7 @@ def test_conv1d_winograd4_persistent(case):
         act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
         ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
     torch.cuda.synchronize()
-    assert _lib.lib().vfx_last_conv_tile() % 100 == 81, "launch did not run on convwg4p_kernel"
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (81, 82), "launch did not run on convwg4p_kernel / convwg4x_kernel"
     _close(yd[:, :, :L], ref, 2e-5)
     assert torch.isnan(yd[:, :, L:]).all()
 
@@ -418,7 +418,7 @@ def test_conv1d_winograd4_persistent_ragged_rows():
             act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
             ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 == 81
+        assert _lib.lib().vfx_last_conv_tile() % 100 in (81, 82)
         for r, n in enumerate(lens):
             if second:
                 ref = F.conv1d(x[r:r + 1, :, :n], w, bias, padding=1) + res[r:r + 1, :, :n]

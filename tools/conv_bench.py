@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--stack", action="store_true", help="1-D k = 3 shapes as the ResStack issues them: dilation 1 = the SECOND convolution of a "
                     "layer (no pre-activation, no post-activation, residual updated in place), otherwise the first (lrelu before and after)")
     ap.add_argument("--wg4", action="store_true", help="offer the Winograd F(4,3) weights (vfx_act.w_wino4; k = 3 1-D shapes; fused C = 64 layers: their second half)")
+    ap.add_argument("--clocks", action="store_true", help="sample shader clock / socket power (bench.ClockSampler) while the timed launches run")
     args = ap.parse_args()
     dev = "cuda"
     B = args.batch
@@ -156,13 +157,29 @@ def main():
         tile = _lib.lib().vfx_last_conv_tile()
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
+        clk = ""
+        if args.clocks:
+            import bench
+            sampler = bench.ClockSampler(torch.cuda.current_device(), period=0.02)
+            with sampler:
+                t0 = time.perf_counter()
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            sm = sampler.summary(t0 + 0.4 * (t1 - t0), t1)
+            if sm.get("sclk_mhz"):
+                clk = "  sclk %4.0f MHz  %4.0f W (n=%d)" % (sm["sclk_mhz"]["mean"], (sm["socket_power_w"] or {"mean": 0})["mean"], sm["sclk_mhz"]["n"])
+        else:
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / args.iters
-        print("%-12s B=%d tile=%d  %8.3f ms  %7.2f TFLOP/s" % (name, B, tile, ms, 2 * macs / ms / 1e9), flush=True)
+        print("%-12s B=%d tile=%d  %8.3f ms  %7.2f TFLOP/s%s" % (name, B, tile, ms, 2 * macs / ms / 1e9, clk), flush=True)
 
 
 if __name__ == "__main__":

@@ -1220,6 +1220,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 #include "vfx_convw.inc"
 #include "vfx_convwg.inc"
 #include "vfx_convwg4p.inc"
+#include "vfx_convwg4x.inc"
 #include "vfx_convwg2d.inc"
 #include "vfx_resblk4.inc"
 
