@@ -796,7 +796,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 96: resblk4_kernel (fused layer, both halves F(4,3)), 16: conv_x3_kernel,
-    # 80 / 81: convwg4_kernel / convwg4p_kernel (Winograd F(4,3), 1-D; one tile per workgroup / persistent), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74 | 91/92/94: fused layer with a Winograd F(2,3) | F(4,3) second half,
+    # 80 / 81 / 82: convwg4_kernel / convwg4p_kernel / convwg4x_kernel (Winograd F(4,3), 1-D; one tile per workgroup / persistent / persistent with the re-blocked wave tile), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74 | 91/92/94: fused layer with a Winograd F(2,3) | F(4,3) second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
     import re
@@ -824,6 +824,12 @@ def main():
             wgm = bm // 32
             return ("wino4", bm, bl, 3, "s"), "convwg4s_kernel<%d,%d,*> (3x3 as Winograd F(4,3) along the map rows, kernel columns share one staged tile)" % (
                 wgm, 4 // wgm), r"convwg4s_kernel<%d, %d, \d+[,>]" % (wgm, 4 // wgm)
+        if code == 82 or (code in (80, 81) and bm == 128):
+            # one family: the Winograd F(4,3) convolutions of the C >= 128 ResStacks and the condnet -- convwg4x_kernel (round 6: 128 channels x 64 quads
+            # per workgroup, 32 x 64 x 6 per wave, deferred epilogue) for the two launches of a ResStack layer, convwg4[p]_kernel<4,1> (128 x 32) for the rest
+            return ("wino4", 128, 128), ("convwg4x_kernel + convwg4[p]_kernel<4,1,*> (Winograd F(4,3) along the dilated axis, 128 output channels per workgroup; "
+                                         "x = 32 x 64 x 6 wave tile with the deferred epilogue, p = persistent workgroups)"), \
+                   r"(convwg4x_kernel<|convwg4p?_kernel<4, 1, (true|false)[,>])"
         if code in (80, 81):   # 81: convwg4p_kernel, the persistent form of the same tile (one family: the same arithmetic on the same tile)
             wgm = bm // 32
             return ("wino4", bm, bl), "convwg4[p]_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; p = persistent workgroups, pipeline across tiles)" % (

@@ -313,7 +313,7 @@ def test_conv1d_winograd4(case):
     ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, rd, wg4=wg4)
     torch.cuda.synchronize()
     assert _lib.lib().vfx_launch_count() == before + 1
-    assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81), "launch did not run on convwg4_kernel"
+    assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81, 82), "launch did not run on convwg4_kernel"
     _close(yd[:, :, :L], ref, 2e-5)
     assert torch.isnan(yd[:, :, L:]).all()
     if use_res and post == _lib.POST_NONE:
@@ -339,7 +339,7 @@ def test_conv1d_winograd4_ragged_rows():
         ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
         ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81)
+        assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81, 82)
         for r, n in enumerate(lens):
             ref = F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil)
             _close(yd[r:r + 1, :, :n], ref, 2e-5)
@@ -388,7 +388,8 @@ def test_conv1d_winograd4_persistent(case):
         act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
         ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
     torch.cuda.synchronize()
-    assert _lib.lib().vfx_last_conv_tile() % 100 in (81, 82), "launch did not run on convwg4p_kernel / convwg4x_kernel"
+    # C >= 128: convwg4x_kernel (round 6: 32 x 64 x 6 wave tile, deferred epilogue), C = 64: convwg4p_kernel<2,2>
+    assert _lib.lib().vfx_last_conv_tile() % 100 == (82 if C >= 128 else 81), "launch did not run on convwg4x_kernel / convwg4p_kernel"
     _close(yd[:, :, :L], ref, 2e-5)
     assert torch.isnan(yd[:, :, L:]).all()
 
@@ -418,7 +419,7 @@ def test_conv1d_winograd4_persistent_ragged_rows():
             act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
             ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 in (81, 82)
+        assert _lib.lib().vfx_last_conv_tile() % 100 == 82
         for r, n in enumerate(lens):
             if second:
                 ref = F.conv1d(x[r:r + 1, :, :n], w, bias, padding=1) + res[r:r + 1, :, :n]
@@ -428,6 +429,38 @@ def test_conv1d_winograd4_persistent_ragged_rows():
                 ref = F.leaky_relu(F.conv1d(F.leaky_relu(x[r:r + 1, :, :n], 0.01), w, bias, dilation=dil, padding=dil), 0.01)
                 _close(yd[r:r + 1, :, :n], ref, 2e-5)
                 assert torch.isnan(yd[r, :, n:]).all()
+
+
+@pytest.mark.parametrize("cfg", [(8, 64, 128, 33003, 3, False), (8, 64, 128, 33002, 1, False), (8, 64, 128, 33001, 1, True),
+                                 (8, 192, 256, 33002, 9, False), (8, 96, 128, 40001, 81, False), (8, 96, 128, 40002, 1, True)])
+def test_conv1d_winograd4_reblocked_short_and_odd_k(cfg):
+    """convwg4x_kernel's deferred epilogue off the happy path: Cin = 64 gives EIGHT 8-channel chunks per tile -- fewer than the nine
+    (one to load + eight to use) the trickle of a finished tile's outputs needs, so the rest is drained un-overlapped in front of the
+    next tile's epilogue; Cin = 192 / 80 put the slot-free second loop at an odd place.  Cin != Cout, odd lengths (the quad that
+    straddles the row's end), NaN canaries past L, the in-place residual."""
+    B, Cin, Cout, L, dil, second = cfg
+    x = _rand((B, Cin, L), 301)
+    w = _rand((Cout, Cin, 3), 302, (Cin * 3) ** -0.5)
+    bias = _rand((Cout,), 303, 0.1)
+    lp = (L + 67) // 4 * 4
+    xd = torch.full((B, Cin, lp), float("nan"), device=DEV)
+    xd[:, :, :L] = x.to(DEV)
+    wp = packing.pack_conv1d(w)
+    wg4 = packing.pack_wino4(wp).to(DEV)
+    if second:
+        res = _rand((B, Cout, L), 304)
+        ref = F.conv1d(x, w, bias, padding=1) + res
+        yd = _padded(res, lp)
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, 1, 0, ops.Act(), yd, wg4=wg4)
+    else:
+        ref = F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.01), w, bias, dilation=dil, padding=dil), 0.01)
+        yd = torch.full((B, Cout, lp), float("nan"), device=DEV)
+        act = ops.Act(pre=_lib.PRE_LRELU, pre_slope=0.01, post=_lib.POST_LRELU, post_slope=0.01)
+        ops.conv1d(xd, wp.to(DEV), bias.to(DEV), yd, L, 3, dil, 0, act, None, wg4=wg4)
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 82, "launch did not run on convwg4x_kernel"
+    _close(yd[:, :, :L], ref, 2e-5)
+    assert torch.isnan(yd[:, :, L:]).all()
 
 
 def test_conv1d_winograd4_fallbacks():
@@ -440,7 +473,7 @@ def test_conv1d_winograd4_fallbacks():
         y2 = torch.full((b2, cout, l2 + 4), float("nan"), device=DEV)
         ops.conv1d(_guarded_nan(x2, 300), wp2.to(DEV), None, y2, l2, 3, 3, 0, None, None, wg4=packing.pack_wino4(wp2).to(DEV))
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 not in (80, 81)
+        assert _lib.lib().vfx_last_conv_tile() % 100 not in (80, 81, 82)
         _close(y2[:, :, :l2], F.conv1d(x2, w2, None, dilation=3, padding=3), 2e-5)
 
 
@@ -1274,7 +1307,7 @@ def test_winograd_kernel_on_adversarial_operand_statistics():
         wp = packing.pack_conv1d(w)
         ops.conv1d(xd, wp.to(DEV), torch.zeros(c, device=DEV), yd, L, 3, 1, 0, None, None, wg4=packing.pack_wino4(wp).to(DEV))
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81), "launch did not run on the Winograd kernel"
+        assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81, 82), "launch did not run on the Winograd kernel"
         y = yd[3, :, :L].cpu().double()
         assert torch.equal(yd[0, :, :L], yd[7, :, :L])         # identical rows: identical bits
         err = y - ref
@@ -1314,6 +1347,6 @@ def test_conv1d_winograd4_long_rows(cfg):
             rd = yd[:, :, :lp]                      # in place
         ops.conv1d(xd[:, :, :lp], wp.to(DEV), bias.to(DEV), yd[:, :, :lp], L, 3, dil, 0, act, rd, wg4=wg4)
         torch.cuda.synchronize()
-        assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81)
+        assert _lib.lib().vfx_last_conv_tile() % 100 in (80, 81, 82)
         _close(yd[:, :, :L], ref0 + res if use_res else ref0, 2e-5)
         assert torch.isnan(yd[:, :, L:]).all()      # nothing written past the rows
