@@ -796,6 +796,7 @@ def main():
     # ---- roofline bookkeeping for the dominant MFMA kernel family (this rank) ----
     # vfx_last_conv_tile() = BM*100000 + BL*100 + code; code 51/52/54: convw_kernel (1-D, chunk depth 8/16/32),
     # 59: convw_kernel 3x3 on pitch maps, 61/62/64: convw_kernel fused ResStack layer, 96: resblk4_kernel (fused layer, both halves F(4,3)), 16: conv_x3_kernel,
+    # 83: convtw_kernel (ConvTranspose1d, Winograd F(3,2)),
     # 80 / 81 / 82: convwg4_kernel / convwg4p_kernel / convwg4x_kernel (Winograd F(4,3), 1-D; one tile per workgroup / persistent / persistent with the re-blocked wave tile), 88: convwg4s_kernel (Winograd F(4,3), 3x3 on pitch maps), 71/72/74 | 91/92/94: fused layer with a Winograd F(2,3) | F(4,3) second half,
     # anything else: conv_taps_kernel with KC = code.  A family = what one regex over rocprofv3's kernel names selects,
     # so that profiles/*kernel_stats*.csv can be averaged over exactly the same launches.
@@ -834,6 +835,10 @@ def main():
             wgm = bm // 32
             return ("wino4", bm, bl), "convwg4[p]_kernel<%d,%d,*> (Winograd F(4,3), %d ch x %d output quads; p = persistent workgroups, pipeline across tiles)" % (
                 wgm, 4 // wgm, bm, bl // 4), r"convwg4p?_kernel<%d, %d, (true|false)[,>]" % (wgm, 4 // wgm)
+        if code == 83:
+            wgm = bm // 32
+            return ("tw32", bm, bl), "convtw_kernel<%d,%d> (ConvTranspose1d as Winograd F(3,2) along the input axis, one output phase per workgroup)" % (
+                wgm, 4 // wgm), r"convtw_kernel<%d, %d>" % (wgm, 4 // wgm)
         if code == 16:
             return ("x3", bm, bl), "conv_x3_kernel<%d,%d,*>" % (bm, bl), r"conv_x3_kernel<%d, %d," % (bm, bl)
         return ("taps", bm, bl, code), "conv_taps_kernel<%d,%d,*,*,KC=%d,*>" % (bm, bl, code), \
@@ -851,6 +856,8 @@ def main():
             return 0.75        # the dilated half direct (3 products per output), the dilation-1 half Winograd F(4,3) (1.5)
         if key[0] == "wfusedw44":
             return 0.5         # both halves Winograd F(4,3)
+        if key[0] == "tw32":
+            return 2.0 / 3.0   # four products per three outputs of a phase; the direct sum has six
         return 1.0
 
     def by_family(events):
@@ -928,7 +935,7 @@ def main():
     if xf != 1.0:
         roofline["algorithm"] = ("Winograd F(4,3) along the dilated axis: 6 fp32 MFMA products per 4 outputs instead of 12; "
                                  "achieved / frac / algorithmic_gflop_per_launch count the EXECUTED products"
-                                 if xf == 0.5 else "fused ResStack layer: dilated half direct, dilation-1 half Winograd on the LDS tile "
+                                 if xf == 0.5 else "ConvTranspose1d as Winograd F(3,2): four products per three outputs instead of six" if abs(xf - 2.0 / 3.0) < 1e-9 else "fused ResStack layer: dilated half direct, dilation-1 half Winograd on the LDS tile "
                                  "(F(4,3): 3 of 4 products, F(2,3): 5 of 6); achieved / frac count the EXECUTED products")
         roofline["direct_conv_gflop_per_launch"] = round(2.0 * macs / launches / 1e9, 3)
         roofline["direct_equivalent_tflops"] = round(2.0 * macs / secs / 1e12, 2)

@@ -100,7 +100,12 @@ typedef struct {
                                along the kernel's ROW axis for each kernel column, 18 slabs kx*6 + plane
                                (packing.py::pack_wino4_2d); launches with Cout % 64 == 0 and Cin % 32 == 0, or Cout % 32
                                == 0 and Cin % 16 == 0, on maps of pitch <= 64 / 128 run on convwg4s_kernel (four
-                               vertically adjacent outputs share 18 products instead of 36). */
+                               vertically adjacent outputs share 18 products instead of 36).  For vfx_convtr1d_f32: the
+                               Winograd F(3,2) transform along the INPUT axis for every output phase r of the polyphase
+                               form (out[q s + r - pad] = w[r + s] x[q - 1] + w[r] x[q]), 4 s slabs 4 r + plane
+                               (packing.py::pack_wino32_tr); launches of >= 512 workgroups with Cin % 32 == 0, Cout % 64
+                               == 0 and no activation run on convtw_kernel: three consecutive q of a phase share four
+                               products instead of six (transform constants 1 and 1/2: rounding as the direct sum's). */
 } vfx_act;
 
 #define VFX_PAD_ZERO 0

@@ -495,6 +495,55 @@ def test_convtr1d_convw(cfg):
     assert torch.isnan(yd[:, :, Lo:]).all()
 
 
+@pytest.mark.parametrize("cfg", [(4, 256, 128, 5000, 3), (2, 512, 256, 2001, 7), (8, 128, 64, 6002, 3), (2, 1024, 512, 1006, 7),
+                                 (3, 64, 128, 4099, 7), (16, 32, 64, 6001, 2)])
+def test_convtr1d_winograd32(cfg):
+    """convtw_kernel (vfx_convtw.inc): the polyphase ConvTranspose1d as Winograd F(3,2) along the input axis -- four products per three
+    outputs of a phase instead of six.  Against torch's direct fp32 conv_transpose1d at the direct kernels' tolerance (the transform
+    constants are 1 and 1/2); input lengths that leave one or two positions in the last triple, both tile shapes (Cout % 128 == 0: 128
+    channels x 32 triples, else 64 x 64), even and odd strides, NaN canaries in the input guard band and past the output's end."""
+    B, Cin, Cout, Lin, s = cfg
+    x = _rand((B, Cin, Lin), 311)
+    w = _rand((Cin, Cout, 2 * s), 312, (2 * Cin) ** -0.5)
+    bias = _rand((Cout,), 313, 0.1)
+    ref = F.conv_transpose1d(x, w, bias, stride=s, padding=s // 2 + s % 2, output_padding=s % 2)
+    xd = _guarded_nan(x, 264)
+    Lo = Lin * s
+    yd = torch.full((B, Cout, (Lo + 67) // 4 * 4), float("nan"), device=DEV)
+    wp = packing.pack_convtr1d(w)
+    ops.convtr1d(xd, wp.to(DEV), bias.to(DEV), yd, Lin, s, None, wd=packing.pack_direct(wp).to(DEV), wg4=packing.pack_wino32_tr(wp, s).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 83, "launch did not run on convtw_kernel"
+    _close(yd[:, :, :Lo], ref, 2e-5)
+    assert torch.isnan(yd[:, :, Lo:]).all()
+    # no bias, and a launch too small for it falls back to the direct kernels with the same result
+    yd2 = torch.full((B, Cout, (Lo + 67) // 4 * 4), float("nan"), device=DEV)
+    ops.convtr1d(xd, wp.to(DEV), None, yd2, Lin, s, None, wd=packing.pack_direct(wp).to(DEV), wg4=packing.pack_wino32_tr(wp, s).to(DEV))
+    torch.cuda.synchronize()
+    _close(yd2[:, :, :Lo], ref - bias[None, :, None], 2e-5)
+
+
+def test_convtr1d_winograd32_ragged_rows():
+    """Per-row input lengths through convtw_kernel: every row equals the same row up-sampled alone, nothing is written past s x its length."""
+    B, Cin, Cout, Lin, s = 6, 256, 128, 7042, 7
+    lens = [7042, 7041, 3521, 1, 2, 5000]
+    x = _rand((B, Cin, Lin), 321)
+    w = _rand((Cin, Cout, 2 * s), 322, (2 * Cin) ** -0.5)
+    bias = _rand((Cout,), 323, 0.1)
+    xd = _guarded_nan(x, 264)
+    ops.with_rows(xd, torch.tensor(lens, dtype=torch.int32, device=DEV))
+    Lo = Lin * s
+    yd = torch.full((B, Cout, (Lo + 67) // 4 * 4), float("nan"), device=DEV)
+    wp = packing.pack_convtr1d(w)
+    ops.convtr1d(xd, wp.to(DEV), bias.to(DEV), yd, Lin, s, None, wd=packing.pack_direct(wp).to(DEV), wg4=packing.pack_wino32_tr(wp, s).to(DEV))
+    torch.cuda.synchronize()
+    assert _lib.lib().vfx_last_conv_tile() % 100 == 83
+    for r, n in enumerate(lens):
+        ref = F.conv_transpose1d(x[r:r + 1, :, :n], w, bias, stride=s, padding=s // 2 + s % 2, output_padding=s % 2)
+        _close(yd[r:r + 1, :, :n * s], ref, 2e-5)
+        assert torch.isnan(yd[r, :, n * s:]).all()
+
+
 def test_convw_small_launches_stay_on_the_first_kernel():
     x = _rand((1, 128, 700), 81)
     w = _rand((128, 128, 3), 82, 0.05)

@@ -134,7 +134,8 @@ def main():
             w3 = packing.pack_x3(wp).to(dev) if args.x3 else None
             bias = torch.zeros(cout, device=dev)
             wd = packing.pack_direct(wp).to(dev) if args.wd else None
-            fn = lambda: ops.convtr1d(x, w, bias, y, L, s, w3=w3, wd=wd)
+            wt = packing.pack_wino32_tr(wp, s).to(dev) if args.wg4 else None      # (--wg4: offer the Winograd F(3,2) planes, convtw_kernel)
+            fn = lambda: ops.convtr1d(x, w, bias, y, L, s, w3=w3, wd=wd, wg4=wt)
             macs = B * L * cin * cout * 2 * s
         else:
             H, lp = L, k

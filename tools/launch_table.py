@@ -58,7 +58,7 @@ def main():
     for (tile, macs, e0, e1), (name, desc) in zip(conv, notes):
         code = tile % 100
         fam = {51: "convw", 52: "convw", 54: "convw", 59: "convw 3x3", 61: "fused", 62: "fused", 64: "fused", 71: "fused+F23", 72: "fused+F23", 74: "fused+F23",
-               91: "fused+F43", 92: "fused+F43", 94: "fused+F43", 96: "fused F43+F43", 80: "convwg4", 81: "convwg4p", 88: "convwg4s", 16: "x3"}.get(code, "conv_taps KC=%d" % code)
+               91: "fused+F43", 92: "fused+F43", 94: "fused+F43", 96: "fused F43+F43", 80: "convwg4", 81: "convwg4p", 82: "convwg4x", 83: "convtw", 88: "convwg4s", 16: "x3"}.get(code, "conv_taps KC=%d" % code)
         ms = e0.elapsed_time(e1)
         if args.taps_only and not fam.startswith("conv_taps"):
             continue

@@ -1221,6 +1221,7 @@ static float* splitk_workspace(hipStream_t s, size_t bytes) {
 #include "vfx_convwg.inc"
 #include "vfx_convwg4p.inc"
 #include "vfx_convwg4x.inc"
+#include "vfx_convtw.inc"
 #include "vfx_convwg2d.inc"
 #include "vfx_resblk4.inc"
 
@@ -1637,6 +1638,10 @@ extern "C" int vfx_convtr1d_f32(const vfx_tensor* x, const float* w_packed, cons
                                 const vfx_act* act, vfx_stream_t stream) {
     // out[o] = x[q]*w[r] + x[q-1]*w[r+s],  u = o + pad = q*s + r   
     if (stride < 1 || stride > VFX_MAXPH) return VFX_EINVAL;
+    if (act && act->w_wino4) {                    // the Winograd F(3,2) form (vfx_convtw.inc): 2/3 of the direct sum's MFMAs
+        const int rc = try_launch_convtw(x, act->w_wino4, bias, y, B, Cin, Cout, Lin, stride, act, (hipStream_t)stream);
+        if (rc != VFX_ENOTSUP) return rc;
+    }
     const int pad = stride / 2 + stride % 2;
     PhaseSpec ph[VFX_MAXPH];
     for (int r = 0; r < stride; ++r) {

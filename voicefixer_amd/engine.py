@@ -141,7 +141,9 @@ class VocoderEngine:
         for j, s in enumerate(weights.UPSAMPLE_SCALES):
             up = "generator.%d.layer" % (3 + 3 * j)
             rs = "generator.%d" % (4 + 3 * j)
-            upw = _wpair(packing.pack_convtr1d(wn(up)), device) + (_dev(sd[up + ".bias"], device),)
+            upp = packing.pack_convtr1d(wn(up))
+            # (w_packed, w_direct, bias, Winograd F(3,2) planes per output phase for convtw_kernel)
+            upw = _wpair(upp, device) + (_dev(sd[up + ".bias"], device), _dev(packing.pack_wino32_tr(upp, s), device))
             layers = []
             cst = weights.VOC_CHANNELS >> (j + 1)
             wino = WINO_MIN_C > 0 and cst >= WINO_MIN_C and cst % 64 == 0
@@ -218,7 +220,8 @@ class VocoderEngine:
                      c * (_up4(Lo) + 2 * (G_DIL + 4)) * 4 < 2 ** 31 - 2 ** 21)
             xs = _rows(B, c, Lo, G_DIL, dev, rows(mult))
             ys = _rows(B, c, Lo, G_DIL if fused else G_TILE, dev, rows(mult))
-            ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1])
+            ops.convtr1d(h, upw[0], upw[2], xs, L, s, self.act_none, w3=self._x3(upw[0]), wd=upw[1],
+                         wg4=_wg(upw[3]) if self.math == "f32" else None)
             if stages is not None:
                 stages["up%d" % (j + 1)] = xs[:, :, :Lo].clone()
             # The fused C = 64 stage runs its WIDELY dilated layers (d > 27: a block of 4 d positions does not fit the fused tile) as two

@@ -161,14 +161,15 @@ def resblock(x, y, w1d, b1, w2d, b2, L, dilation, slope=0.01, post=POST_NONE, po
     _prof_end(e0, 2 * B * L * Cn * Cn * 3)
 
 
-def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None, wd=None):
+def convtr1d(x, w, bias, y, Lin, stride, act=None, w3=None, wd=None, wg4=None):
+    """``wg4`` (packing.pack_wino32_tr on the device) offers the launch the Winograd F(3,2) kernel (convtw_kernel)."""
     _need_cuda(x, w, y, bias)
     B, cin = x.shape[0], x.shape[1]
     cout = w.shape[2]
     xd, yd = tdesc(x), tdesc(y)
     e0 = _prof_begin()
     rc = _lib.lib().vfx_convtr1d_f32(C.byref(xd), _ptr(w), _ptr(bias), C.byref(yd), B, cin, cout, Lin, stride,
-                                     _act(act, w3, wd), _stream())
+                                     _act(act, w3, wd, wg4), _stream())
     check(rc, "vfx_convtr1d_f32")
     _prof_end(e0, B * Lin * cin * cout * 2 * stride)
 

@@ -73,6 +73,20 @@ def pack_wino4(w_packed):
     return pack_direct(u.float())
 
 
+def pack_wino32_tr(w_packed, stride):
+    """[2 s][CinPad][Cout] (tap slabs of a polyphase ConvTranspose1d, kernel 2 s, stride s: out[q s + r - pad] = w[r + s] x[q - 1] +
+    w[r] x[q]) -> [4 s][CinPad/8][Cout][8], slab 4 r + plane: for every output phase r the Winograd F(3,2) weight transform along the
+    INPUT axis, U0 = g0, U1 = (g0 + g1) / 2, U2 = (g0 - g1) / 2, U3 = g1 with g0 = w[r + s], g1 = w[r] (float64, rounded once), in the
+    A-operand layout of pack_direct: convtw_kernel (vfx_act.w_wino4 of vfx_convtr1d_f32)."""
+    assert w_packed.shape[0] == 2 * stride
+    g = w_packed.double()
+    planes = []
+    for r in range(stride):
+        g0, g1 = g[r + stride], g[r]
+        planes += [g0, (g0 + g1) * 0.5, (g0 - g1) * 0.5, g1]
+    return pack_direct(torch.stack(planes).float())
+
+
 def _f43(g0, g1, g2):
     return [g0 / 4, -(g0 + g1 + g2) / 6, -(g0 - g1 + g2) / 6, g0 / 24 + g1 / 12 + g2 / 6, g0 / 24 - g1 / 12 + g2 / 6, g2]
 
