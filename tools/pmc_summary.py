@@ -45,7 +45,7 @@ def hbm(fetch_csv, write_csv, out):
     w, nw = read(write_csv)
     res = {}
     for k in f:
-        if k not in w or not any(t in k for t in ("conv_taps", "convw", "resblk", "gru", "stft", "conv_cout1")):
+        if k not in w or not any(t in k for t in ("conv_taps", "convw", "convtw", "resblk", "gru", "stft", "conv_cout1")):
             continue
         fa = f[k]["FETCH_SIZE"] / nf[k]
         wa = w[k]["WRITE_SIZE"] / nw[k]
@@ -80,7 +80,7 @@ def mfma(m_csv, out, trace_csv=None):
     dur = durations(trace_csv)[0] if trace_csv else {}
     res = {}
     for k, c in m.items():
-        if not any(t in k for t in ("conv_taps", "convw", "resblk", "gru", "stft", "conv_cout1")):
+        if not any(t in k for t in ("conv_taps", "convw", "convtw", "resblk", "gru", "stft", "conv_cout1")):
             continue
         gui = c.get("GRBM_GUI_ACTIVE", 0.0)
         if gui <= 0:
