@@ -786,7 +786,8 @@ def main():
 
     per_rank = [{"rank": 0, "device": "cuda:%d" % dev.index, "wall_s": round(dt, 4)}]
     if dist is not None:
-        mine = torch.tensor([dt, float(dev.index)], device=dev, dtype=torch.float64)
+        xdev = dev if dist.get_backend() == "nccl" else None      # (the --oversubscribe rehearsal runs its collectives on gloo: host tensors)
+        mine = torch.tensor([dt, float(dev.index)], device=xdev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = [{"rank": r, "device": "cuda:%d" % int(x[1]), "wall_s": round(float(x[0]), 4)}
@@ -964,7 +965,8 @@ def main():
     value = audio_seconds / dt
     line = {
         "metric": "seconds-of-44.1kHz-audio restored per wall-second",
-        "value": round(value, 2), "unit": "x real-time", "n_gpus": world, "steps": args.steps,
+        # n_gpus counts DISTINCT devices (an --oversubscribe rehearsal puts several ranks on one); `ranks` = processes that ran
+        "value": round(value, 2), "unit": "x real-time", "n_gpus": len({pr["device"] for pr in per_rank}), "ranks": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.math, "data": "synthetic",
         "value_definition": ("whole-job audio seconds per wall second with the inputs resident in HBM when the timed region "
@@ -999,7 +1001,7 @@ def main():
     if dt_single is not None:
         dts = dt_single
         if dist is not None:
-            t = torch.tensor([dt_single], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt_single], device=dev if dist.get_backend() == "nccl" else None, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t.item())
         line["single_stream"] = {"value": round(audio_seconds / dts, 2), "unit": "x real-time",

@@ -968,6 +968,27 @@ def test_bench_oversubscribed_folder_job_two_ranks_on_one_device(tmp_path):
         assert cpus[0]["cores"] != cpus[1]["cores"] and all(c["torch_threads"] == min(c["n_physical"], 16) for c in cpus)
 
 
+def test_bench_oversubscribed_weak_scaling_line_carries_the_one_rank_leg():
+    """``bench.py --gpus 2 --oversubscribe`` (no folder): the weak-scaling line the driver runs at N > 1, rehearsed with two launcher ranks on
+    this box's one GPU (gloo for the collectives): rank 0 first runs the K steps alone (``one_rank_leg``), the line carries the self-measured
+    efficiency beside ``value`` and counts distinct devices."""
+    import json
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("the rehearsal is for one-GPU boxes (test_bench_two_devices_... covers the real thing)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--oversubscribe", "--batch", "4", "--steps", "2",
+                        "--warmup", "1", "--no-bf16x3"], cwd=root, capture_output=True, text=True, timeout=900, env=dict(os.environ, PYTHONPATH=root))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["ranks"] == 2 and j["rccl"]["backend"] == "gloo" and len(j["per_rank"]) == 2
+    assert j["one_rank_leg"]["value"] > 0 and 0.2 < j["scaling_efficiency_self_measured"] < 1.2
+    assert j["value"] > 10 and "roofline" in j and "clocks" in j
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two HIP devices (the first real N > 1 run: lights up on a multi-GPU lease)")
 def test_bench_two_devices_on_rccl_folder_and_weak_scaling_lines():
     """On a node with >= 2 GPUs: ``bench.py --gpus 2 --synth-folder 32`` (BASELINE configs[3] disk to disk, RCCL for the counters) and
