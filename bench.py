@@ -661,9 +661,11 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     dev = torch.device("cuda", torch.cuda.current_device())
     dist = None
-    if world > 1 and (args.synth_folder or args.folder):
-        # the folder job runs decode / encode workers next to the interpreter: every rank gets its own core slice, BEFORE the
-        # process group exists (its threads inherit the mask) -- what `python -m voicefixer_amd --gpus N` does (__main__.py)
+    if world > 1:
+        # every rank of a node gets its own slice of physical cores, BEFORE the process group exists (its threads inherit the mask):
+        # the folder job runs decode / encode workers next to the interpreter, and every job packs ~100 M weights on the host at
+        # start-up -- eight ranks with a host's worth of ATen threads each would fight over the cores (`python -m voicefixer_amd
+        # --gpus N` does the same, __main__.py)
         from voicefixer_amd import dist as vdist_
         vdist_.pin_rank_cpus(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     if world > 1 or args.scatter or ((args.synth_folder or args.folder) and "WORLD_SIZE" in os.environ):
