@@ -63,3 +63,21 @@ def test_folder_job_on_two_ranks_with_a_stub_device_stage():
     if len(os.sched_getaffinity(0)) >= 4:
         assert all(c["pinned"] for c in cpus) and cpus[0]["cores"] != cpus[1]["cores"]
         assert all(c["torch_threads"] == min(c["n_physical"], 16) for c in cpus)
+
+
+def test_clock_sampler_and_core_ranges_do_not_need_a_gpu():
+    """bench.ClockSampler (sclk / socket power beside every bench line) must never break a run: without a HIP device it finds no hwmon of
+    its own (or only rocm-smi, which reports nothing) and says so; its summary keeps the samples inside the window it is asked for."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    smp = bench.ClockSampler(0, period=0.01)
+    with smp:
+        time.sleep(0.05)
+    doc = smp.summary()
+    assert "source" in doc and (doc["source"] is None or doc.get("sclk_mhz") is None or doc["sclk_mhz"]["n"] >= 1)
+    smp.source, smp.samples = "fake", [(1.0, 2100.0, 1300.0), (2.0, 2200.0, None), (3.0, None, 1400.0), (9.0, 999.0, 999.0)]
+    doc = smp.summary(0.5, 3.5)
+    assert doc["sclk_mhz"] == {"mean": 2150.0, "min": 2100.0, "max": 2200.0, "n": 2}
+    assert doc["socket_power_w"] == {"mean": 1350.0, "min": 1300.0, "max": 1400.0, "n": 2}
+    assert bench._ranges([0, 1, 2, 3, 128, 129, 200]) == "0-3,128-129,200" and bench._ranges([]) is None
